@@ -1,0 +1,118 @@
+"""Destination-sorted CSR of a PyG-style edge_index, built on the GPU once per mesh.
+
+Replaces the per-call index handling of `scatter_mean(graph.edge_attr, dest_indices, ...)`
+(/root/reference/src/mpn/message_passing_modules.py:46-48,67-68).  The sort is stable, so inside a
+destination's row the edges keep the reference's edge order.
+"""
+from __future__ import annotations
+
+import weakref
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+
+@dataclass
+class CSR:
+    num_nodes: int
+    num_edges: int
+    rowptr: torch.Tensor      # int32 [N+1]
+    src_sorted: torch.Tensor  # int32 [E]
+    dst_sorted: torch.Tensor  # int32 [E]
+    perm: torch.Tensor        # int32 [E]: original edge id at sorted position p
+
+
+def _require_cuda(t: torch.Tensor, name: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"amber_amd: `{name}` is on {t.device}; the MPN path runs on MI355X only (move the batch to "
+            f"'cuda'). There is no CPU path."
+        )
+
+
+def build_csr(edge_index: torch.Tensor, num_nodes: int, validate: bool = True) -> CSR:
+    """Build the CSR for edge_index[2, E] (row 0 = source, row 1 = destination).
+
+    `validate=True` reads back one status word (a device synchronisation, once per mesh) and raises
+    IndexError when an index lies outside [0, num_nodes), the error torch indexing would raise.
+    """
+    lib = _lib.load()
+    _require_cuda(edge_index, "edge_index")
+    if edge_index.dim() != 2 or edge_index.shape[0] != 2:
+        raise ValueError(f"Edge index must have shape (2, num_edges), given '{tuple(edge_index.shape)}' instead.")
+    ei = edge_index.long().contiguous()
+    dev = ei.device
+    E, N = int(ei.shape[1]), int(num_nodes)
+    rowptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
+    src_sorted = torch.empty(E, dtype=torch.int32, device=dev)
+    dst_sorted = torch.empty(E, dtype=torch.int32, device=dev)
+    perm = torch.empty(E, dtype=torch.int32, device=dev)
+    status = torch.empty(1, dtype=torch.int32, device=dev)
+    ws_bytes = lib.amber_mpn_csr_workspace_bytes(N, E)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.amber_mpn_csr_build(ei.data_ptr(), E, N, rowptr.data_ptr(), src_sorted.data_ptr(), dst_sorted.data_ptr(),
+                                     perm.data_ptr(), status.data_ptr(), ws.data_ptr(), ws_bytes, _lib.stream_ptr(dev))
+    _lib.check(rc, "csr_build")
+    if validate and int(status.item()) != 0:
+        raise IndexError(f"edge_index contains node ids outside [0, {N})")
+    return CSR(N, E, rowptr, src_sorted, dst_sorted, perm)
+
+
+class CSRCache:
+    """Remembers the CSR of the last few edge_index tensors ("sorted once per mesh").
+
+    A hit needs the SAME tensor object, unmodified (`_version`), so a recycled address cannot alias."""
+
+    def __init__(self, capacity: int = 4):
+        self.capacity = capacity
+        self._entries = []  # (weakref(tensor), version, num_nodes, CSR)
+
+    def get(self, edge_index: torch.Tensor, num_nodes: int) -> CSR:
+        for ref, version, n, csr in self._entries:
+            if ref() is edge_index and version == edge_index._version and n == num_nodes:
+                return csr
+        csr = build_csr(edge_index, num_nodes)
+        self._entries = [e for e in self._entries if e[0]() is not None][-(self.capacity - 1):] if self.capacity > 1 else []
+        self._entries.append((weakref.ref(edge_index), edge_index._version, num_nodes, csr))
+        return csr
+
+
+def csr_of(graph, num_nodes: int, cache: Optional[CSRCache]) -> CSR:
+    """CSR for a graph: an `amber_csr` attribute set by the caller wins, else the cache, else a fresh build."""
+    pre = getattr(graph, "amber_csr", None)
+    if isinstance(pre, CSR) and pre.num_nodes == num_nodes and pre.num_edges == int(graph.edge_index.shape[1]):
+        return pre
+    if cache is not None:
+        return cache.get(graph.edge_index, num_nodes)
+    return build_csr(graph.edge_index, num_nodes)
+
+
+def segment_mean(values_sorted: torch.Tensor, rowptr: torch.Tensor) -> torch.Tensor:
+    """Deterministic CSR segmented mean (scatter_mean on destination-sorted rows; zero-degree rows -> 0)."""
+    lib = _lib.load()
+    _require_cuda(values_sorted, "values")
+    v = values_sorted.float().contiguous()
+    n = int(rowptr.shape[0]) - 1
+    out = torch.empty(n, v.shape[1], dtype=torch.float32, device=v.device)
+    with torch.cuda.device(v.device):
+        rc = lib.amber_mpn_segment_mean(v.data_ptr(), rowptr.data_ptr(), n, int(v.shape[0]), int(v.shape[1]), out.data_ptr(),
+                                        _lib.stream_ptr(v.device))
+    _lib.check(rc, "segment_mean")
+    return out
+
+
+def permute_rows(rows: torch.Tensor, perm: torch.Tensor, gather: bool) -> torch.Tensor:
+    """gather: out[p] = rows[perm[p]] (edge_index order -> CSR order); else out[perm[p]] = rows[p]."""
+    lib = _lib.load()
+    _require_cuda(rows, "rows")
+    r = rows.float().contiguous()
+    out = torch.empty_like(r)
+    with torch.cuda.device(r.device):
+        rc = lib.amber_mpn_permute_rows(r.data_ptr(), perm.data_ptr(), int(r.shape[0]), int(r.shape[1]), 1 if gather else 0,
+                                        out.data_ptr(), _lib.stream_ptr(r.device))
+    _lib.check(rc, "permute_rows")
+    return out

@@ -1,0 +1,642 @@
+// Host side of libamber_mpn.so: parameter layout, workspace carving, launch sequencing, C ABI.
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "mpn_internal.h"
+
+namespace amber {
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  return code;
+}
+int fail_hip(hipError_t e, const char* what) {
+  return fail(AMBER_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+}
+#define HIP_TRY(expr, what)                          \
+  do {                                               \
+    hipError_t _e = (expr);                          \
+    if (_e != hipSuccess) return fail_hip(_e, what); \
+  } while (0)
+
+inline size_t align256(size_t x) { return (x + 255) & ~static_cast<size_t>(255); }
+inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---------------------------------------------------------------------------------------------------
+// parameter layout (offsets in floats into `params` and `packed`), see include/amber_mpn.h
+// ---------------------------------------------------------------------------------------------------
+struct MlpLayout {
+  int64_t W[kMaxLayers];   // params offset of layer weight
+  int64_t B[kMaxLayers];   // params offset of layer bias
+  int64_t P[kMaxLayers];   // params offset of post-norm parameter 0 (decoder) or -1
+  int64_t Q[kMaxLayers];
+  int64_t PW[kMaxLayers][3];  // packed offsets: layer 0 may have up to 3 column blocks, layers >= 1 use [0]
+  int32_t layers;
+  int32_t in_cols;            // columns of layer 0
+};
+struct Layout {
+  MlpLayout node_embed, edge_embed;
+  std::vector<MlpLayout> edge, node;
+  std::vector<int64_t> eg, eb, ng, nb;  // LayerNorm params per step (or -1)
+  MlpLayout dec;
+  int64_t readout_w, readout_b;
+  int64_t n_params, n_packed;
+};
+
+int validate(const AmberMpnDesc* d) {
+  if (!d) return fail(AMBER_ERR_INVALID_ARGUMENT, "desc is NULL");
+  if (d->latent != 32 && d->latent != 64 && d->latent != 128)
+    return fail(AMBER_ERR_UNSUPPORTED, "latent_dimension %d not supported (32, 64, 128)", d->latent);
+  if (d->num_steps < 0 || d->num_step_repeats < 1) return fail(AMBER_ERR_INVALID_ARGUMENT, "bad num_steps / num_step_repeats");
+  if (d->mlp_layers < 1 || d->mlp_layers > kMaxLayers)
+    return fail(AMBER_ERR_UNSUPPORTED, "stack.mlp.num_layers %d not in 1..%d", d->mlp_layers, kMaxLayers);
+  if (d->activation < AMBER_ACT_RELU || d->activation > AMBER_ACT_TANH)
+    return fail(AMBER_ERR_UNSUPPORTED, "LatentMLP activation id %d (relu, leakyrelu, tanh only)", d->activation);
+  if (d->residual < 0 || d->residual > 2 || d->layer_norm < 0 || d->layer_norm > 2)
+    return fail(AMBER_ERR_INVALID_ARGUMENT, "bad residual / layer_norm mode");
+  if (d->in_node_features < 0 || d->in_node_features > 64 || d->in_edge_features < 0 || d->in_edge_features > 64)
+    return fail(AMBER_ERR_UNSUPPORTED, "raw feature widths must be in 0..64");
+  if (d->embed_layers < 0 || d->embed_layers > kMaxLayers) return fail(AMBER_ERR_UNSUPPORTED, "embed_layers out of range");
+  if (d->embed_layers > 0 && (d->embed_activation < AMBER_ACT_RELU || d->embed_activation > AMBER_ACT_TANH))
+    return fail(AMBER_ERR_UNSUPPORTED, "embedding MLP activation id %d", d->embed_activation);
+  if (d->has_head) {
+    if (d->decoder_layers < 0 || d->decoder_layers > kMaxLayers) return fail(AMBER_ERR_UNSUPPORTED, "decoder_layers out of range");
+    if (d->decoder_activation < AMBER_ACT_RELU || d->decoder_activation > AMBER_ACT_GELU)
+      return fail(AMBER_ERR_UNSUPPORTED, "decoder activation id %d", d->decoder_activation);
+    if (d->decoder_norm < 0 || d->decoder_norm > 2) return fail(AMBER_ERR_INVALID_ARGUMENT, "bad decoder_norm");
+  }
+  if (d->precision != AMBER_PREC_FP32) return fail(AMBER_ERR_UNSUPPORTED, "precision id %d", d->precision);
+  if (!(d->ln_eps > 0.f)) return fail(AMBER_ERR_INVALID_ARGUMENT, "ln_eps must be > 0");
+  return AMBER_OK;
+}
+
+Layout build_layout(const AmberMpnDesc& d) {
+  Layout lay;
+  const int64_t L = d.latent;
+  int64_t po = 0, pk = 0;
+  auto mlp = [&](MlpLayout& m, int layers, int in_cols, int col_blocks, bool norm, bool pack_first) {
+    m.layers = layers;
+    m.in_cols = in_cols;
+    for (int l = 0; l < kMaxLayers; ++l) {
+      m.W[l] = m.B[l] = m.P[l] = m.Q[l] = -1;
+      m.PW[l][0] = m.PW[l][1] = m.PW[l][2] = -1;
+    }
+    for (int l = 0; l < layers; ++l) {
+      const int64_t cols = l == 0 ? in_cols : L;
+      m.W[l] = po;
+      po += L * cols;
+      m.B[l] = po;
+      po += L;
+      if (norm) {
+        m.P[l] = po;
+        po += L;
+        m.Q[l] = po;
+        po += L;
+      }
+      if (l == 0) {
+        if (pack_first)
+          for (int cb = 0; cb < col_blocks; ++cb) {
+            m.PW[0][cb] = pk;
+            pk += L * L;
+          }
+      } else {
+        m.PW[l][0] = pk;
+        pk += L * L;
+      }
+    }
+  };
+  auto embed = [&](MlpLayout& m, int F) {
+    if (F == 0) {  // EmptyLinear: bias only
+      m.layers = 0;
+      m.in_cols = 0;
+      for (int l = 0; l < kMaxLayers; ++l) m.W[l] = m.B[l] = m.P[l] = m.Q[l] = m.PW[l][0] = m.PW[l][1] = m.PW[l][2] = -1;
+      m.B[0] = po;
+      po += L;
+    } else {
+      mlp(m, d.embed_layers > 0 ? d.embed_layers : 1, F, 0, false, false);
+    }
+  };
+  embed(lay.node_embed, d.in_node_features);
+  embed(lay.edge_embed, d.in_edge_features);
+  lay.edge.resize(d.num_steps);
+  lay.node.resize(d.num_steps);
+  lay.eg.assign(d.num_steps, -1);
+  lay.eb.assign(d.num_steps, -1);
+  lay.ng.assign(d.num_steps, -1);
+  lay.nb.assign(d.num_steps, -1);
+  for (int s = 0; s < d.num_steps; ++s) {
+    mlp(lay.edge[s], d.mlp_layers, 3 * d.latent, 3, false, true);
+    mlp(lay.node[s], d.mlp_layers, 2 * d.latent, 2, false, true);
+    if (d.layer_norm != AMBER_MODE_NONE) {
+      lay.eg[s] = po;
+      po += L;
+      lay.eb[s] = po;
+      po += L;
+      lay.ng[s] = po;
+      po += L;
+      lay.nb[s] = po;
+      po += L;
+    }
+  }
+  lay.dec.layers = 0;
+  lay.readout_w = lay.readout_b = -1;
+  if (d.has_head) {
+    mlp(lay.dec, d.decoder_layers, d.latent, 1, d.decoder_norm != AMBER_NORM_NONE, true);
+    lay.readout_w = po;
+    po += L;
+    lay.readout_b = po;
+    po += 1;
+  }
+  lay.n_params = po;
+  lay.n_packed = pk;
+  return lay;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// workspace
+// ---------------------------------------------------------------------------------------------------
+struct Workspace {
+  float *x, *e, *Ps, *Pd, *agg, *head, *tail;
+  size_t bytes;
+};
+Workspace carve(const AmberMpnDesc& d, int64_t N, int64_t E, void* base) {
+  const size_t L = static_cast<size_t>(d.latent);
+  const size_t T = static_cast<size_t>(cdiv(E, kTile));
+  const size_t nb = align256(sizeof(float) * static_cast<size_t>(N) * L);
+  const size_t ebytes = align256(sizeof(float) * static_cast<size_t>(E) * L);
+  const size_t tb = align256(sizeof(float) * T * L);
+  char* p = static_cast<char*>(base);
+  Workspace w;
+  size_t off = 0;
+  auto take = [&](size_t n) {
+    float* r = reinterpret_cast<float*>(p + off);
+    off += n;
+    return r;
+  };
+  w.x = take(nb);
+  w.Ps = take(nb);
+  w.Pd = take(nb);
+  w.agg = take(nb);
+  w.head = take(tb);
+  w.tail = take(tb);
+  w.e = take(ebytes);
+  w.bytes = off;
+  return w;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// optional per-kernel timing (bench hook)
+// ---------------------------------------------------------------------------------------------------
+struct Timer {
+  bool on = false;
+  hipStream_t s = nullptr;
+  struct Rec {
+    hipEvent_t a, b;
+    int cls;
+  };
+  std::vector<Rec> recs;
+  void begin(int cls) {
+    if (!on) return;
+    Rec r;
+    r.cls = cls;
+    hipEventCreate(&r.a);
+    hipEventCreate(&r.b);
+    hipEventRecord(r.a, s);
+    recs.push_back(r);
+  }
+  void end() {
+    if (!on) return;
+    hipEventRecord(recs.back().b, s);
+  }
+  void collect(float* ms, int32_t* launches) {
+    for (int i = 0; i < AMBER_MPN_NUM_KERNEL_CLASSES; ++i) {
+      ms[i] = 0.f;
+      if (launches) launches[i] = 0;
+    }
+    hipStreamSynchronize(s);
+    for (auto& r : recs) {
+      float t = 0.f;
+      hipEventElapsedTime(&t, r.a, r.b);
+      ms[r.cls] += t;
+      if (launches) launches[r.cls] += 1;
+      hipEventDestroy(r.a);
+      hipEventDestroy(r.b);
+    }
+    recs.clear();
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------
+// argument builders
+// ---------------------------------------------------------------------------------------------------
+void fill_edge_step(EdgeArgs& a, const AmberMpnDesc& d, const Layout& lay, int step, const float* params, const float* packed) {
+  const MlpLayout& m = lay.edge[step];
+  a.w0e = packed + m.PW[0][2];
+  a.nl = d.mlp_layers;
+  a.act = d.activation;
+  for (int l = 1; l < d.mlp_layers; ++l) a.layers[l] = DenseLayer{packed + m.PW[l][0], params + m.B[l], nullptr, nullptr};
+  a.residual = d.residual;
+  a.layer_norm = d.layer_norm;
+  a.gamma = d.layer_norm != AMBER_MODE_NONE ? params + lay.eg[step] : nullptr;
+  a.beta = d.layer_norm != AMBER_MODE_NONE ? params + lay.eb[step] : nullptr;
+  a.eps = d.ln_eps;
+}
+void fill_node_update(NodeArgs& a, const AmberMpnDesc& d, const Layout& lay, int step, const float* params, const float* packed) {
+  const MlpLayout& m = lay.node[step];
+  a.do_update = 1;
+  a.w0x = packed + m.PW[0][0];
+  a.w0a = packed + m.PW[0][1];
+  a.b0 = params + m.B[0];
+  a.nl = d.mlp_layers;
+  a.act = d.activation;
+  for (int l = 1; l < d.mlp_layers; ++l) a.layers[l] = DenseLayer{packed + m.PW[l][0], params + m.B[l], nullptr, nullptr};
+  a.residual = d.residual;
+  a.layer_norm = d.layer_norm;
+  a.gamma = d.layer_norm != AMBER_MODE_NONE ? params + lay.ng[step] : nullptr;
+  a.beta = d.layer_norm != AMBER_MODE_NONE ? params + lay.nb[step] : nullptr;
+  a.eps = d.ln_eps;
+}
+void fill_node_proj(NodeArgs& a, const Layout& lay, int step, const float* params, const float* packed, float* Ps, float* Pd) {
+  const MlpLayout& m = lay.edge[step];
+  a.do_proj = 1;
+  a.w0s = packed + m.PW[0][0];
+  a.w0d = packed + m.PW[0][1];
+  a.b0e = params + m.B[0];
+  a.Ps = Ps;
+  a.Pd = Pd;
+}
+void fill_node_head(NodeArgs& a, const AmberMpnDesc& d, const Layout& lay, const float* params, const float* packed,
+                    const int32_t* out_index, float* out) {
+  a.n_dense = d.decoder_layers;
+  a.dense_act = d.decoder_activation;
+  a.dense_norm = d.decoder_norm;
+  for (int l = 0; l < d.decoder_layers; ++l)
+    a.dense[l] = DenseLayer{packed + lay.dec.PW[l][0], params + lay.dec.B[l], lay.dec.P[l] >= 0 ? params + lay.dec.P[l] : nullptr,
+                            lay.dec.Q[l] >= 0 ? params + lay.dec.Q[l] : nullptr};
+  a.do_readout = 1;
+  a.wr = params + lay.readout_w;
+  a.br = params + lay.readout_b;
+  a.out_index = out_index;
+  a.out = out;
+}
+
+// one Embedding module: linear / constant / MLP, rows optionally gathered through perm; result in `out`
+int run_embedding(const AmberMpnDesc& d, const MlpLayout& m, int F, const float* params, const float* packed, const float* in,
+                  int64_t rows, const int32_t* perm, float* out, hipStream_t s, Timer& tm) {
+  const int L = d.latent;
+  tm.begin(AMBER_KC_EMBED);
+  hipError_t e;
+  if (F == 0)
+    e = launch_embed(L, nullptr, rows, 0, nullptr, params + m.B[0], nullptr, -1, out, s);
+  else
+    e = launch_embed(L, in, rows, F, params + m.W[0], params + m.B[0], perm, d.embed_layers > 0 ? d.embed_activation : -1, out, s);
+  tm.end();
+  HIP_TRY(e, "embed kernel");
+  if (F > 0 && d.embed_layers > 1) {
+    NodeArgs a{};
+    a.N = rows;
+    a.x_in = out;
+    a.n_dense = d.embed_layers - 1;
+    a.dense_act = d.embed_activation;
+    a.dense_norm = AMBER_NORM_NONE;
+    for (int l = 1; l < d.embed_layers; ++l) a.dense[l - 1] = DenseLayer{packed + m.PW[l][0], params + m.B[l], nullptr, nullptr};
+    a.dense_out = out;  // in place: a wave reads its 32 rows before it writes them
+    tm.begin(AMBER_KC_EMBED);
+    e = launch_node(L, a, s);
+    tm.end();
+    HIP_TRY(e, "embedding MLP kernel");
+  }
+  return AMBER_OK;
+}
+
+int forward_impl(const AmberMpnDesc* desc, const float* params, const float* packed, int64_t N, int64_t E, const float* x,
+                 const float* edge_attr, const int32_t* rowptr, const int32_t* src_sorted, const int32_t* dst_sorted,
+                 const int32_t* perm, const int32_t* out_index, float* out_node, float* out_edge, float* out_sizing,
+                 void* workspace, size_t workspace_bytes, hipStream_t s, Timer& tm) {
+  int rc = validate(desc);
+  if (rc) return rc;
+  const AmberMpnDesc& d = *desc;
+  if (N < 0 || E < 0 || N >= (1ll << 31) || E >= (1ll << 31)) return fail(AMBER_ERR_INVALID_ARGUMENT, "N / E out of int32 range");
+  if (!params || !packed || !workspace) return fail(AMBER_ERR_INVALID_ARGUMENT, "params / packed / workspace is NULL");
+  if (N > 0 && d.in_node_features > 0 && !x) return fail(AMBER_ERR_INVALID_ARGUMENT, "x is NULL");
+  if (E > 0 && d.in_edge_features > 0 && !edge_attr) return fail(AMBER_ERR_INVALID_ARGUMENT, "edge_attr is NULL");
+  if (E > 0 && (!rowptr || !src_sorted || !dst_sorted || !perm)) return fail(AMBER_ERR_INVALID_ARGUMENT, "CSR arrays are NULL");
+  if (N > 0 && !rowptr) return fail(AMBER_ERR_INVALID_ARGUMENT, "rowptr is NULL");
+  if (out_sizing && !d.has_head) return fail(AMBER_ERR_INVALID_ARGUMENT, "out_sizing requested but desc->has_head == 0");
+  if (workspace_bytes < amber_mpn_workspace_bytes(desc, N, E))
+    return fail(AMBER_ERR_WORKSPACE_TOO_SMALL, "workspace %zu < %zu bytes", workspace_bytes, amber_mpn_workspace_bytes(desc, N, E));
+  if (N == 0) return AMBER_OK;  // an edge needs nodes: nothing to compute
+  const Layout lay = build_layout(d);
+  const Workspace w = carve(d, N, E, workspace);
+  const int L = d.latent;
+
+  rc = run_embedding(d, lay.node_embed, d.in_node_features, params, packed, x, N, nullptr, w.x, s, tm);
+  if (rc) return rc;
+  rc = run_embedding(d, lay.edge_embed, d.in_edge_features, params, packed, edge_attr, E, perm, w.e, s, tm);
+  if (rc) return rc;
+
+  const int iters = d.num_steps * d.num_step_repeats;
+  const bool want_head = d.has_head && out_sizing;
+  if (iters == 0) {
+    NodeArgs a{};
+    a.N = N;
+    a.x_in = w.x;
+    a.x_out = out_node;
+    if (want_head) fill_node_head(a, d, lay, params, packed, out_index, out_sizing);
+    if (out_node || want_head) {
+      tm.begin(AMBER_KC_NODE);
+      hipError_t e = launch_node(L, a, s);
+      tm.end();
+      HIP_TRY(e, "node kernel");
+    }
+    if (out_edge) {
+      tm.begin(AMBER_KC_OTHER);
+      hipError_t e = launch_permute_rows(w.e, perm, E, L, 0, out_edge, s);
+      tm.end();
+      HIP_TRY(e, "permute kernel");
+    }
+    return AMBER_OK;
+  }
+  {  // first-layer projections of step 0
+    NodeArgs a{};
+    a.N = N;
+    a.x_in = w.x;
+    fill_node_proj(a, lay, 0, params, packed, w.Ps, w.Pd);
+    tm.begin(AMBER_KC_NODE);
+    hipError_t e = launch_node(L, a, s);
+    tm.end();
+    HIP_TRY(e, "node projection kernel");
+  }
+  for (int it = 0; it < iters; ++it) {
+    const int step = it / d.num_step_repeats;
+    const bool last = it == iters - 1;
+    EdgeArgs ea{};
+    ea.E = E;
+    ea.N = N;
+    ea.src = src_sorted;
+    ea.dst = dst_sorted;
+    ea.rowptr = rowptr;
+    ea.perm = perm;
+    ea.e = w.e;
+    ea.Ps = w.Ps;
+    ea.Pd = w.Pd;
+    fill_edge_step(ea, d, lay, step, params, packed);
+    ea.agg = w.agg;
+    ea.head = w.head;
+    ea.tail = w.tail;
+    ea.write_e = last ? 0 : 1;  // after the last step only the aggregate (and out_edge, if asked for) is needed
+    ea.out_edge = last ? out_edge : nullptr;
+    tm.begin(AMBER_KC_EDGE);
+    hipError_t e = launch_edge(L, ea, s);
+    tm.end();
+    HIP_TRY(e, "edge kernel");
+
+    NodeArgs na{};
+    na.N = N;
+    na.x_in = w.x;
+    na.rowptr = rowptr;
+    na.agg = w.agg;
+    na.head = w.head;
+    na.tail = w.tail;
+    fill_node_update(na, d, lay, step, params, packed);
+    if (!last) {
+      na.x_out = w.x;
+      fill_node_proj(na, lay, (it + 1) / d.num_step_repeats, params, packed, w.Ps, w.Pd);
+    } else {
+      na.x_out = out_node;
+      if (want_head) fill_node_head(na, d, lay, params, packed, out_index, out_sizing);
+    }
+    tm.begin(AMBER_KC_NODE);
+    e = launch_node(L, na, s);
+    tm.end();
+    HIP_TRY(e, "node kernel");
+  }
+  return AMBER_OK;
+}
+
+}  // namespace
+}  // namespace amber
+
+using namespace amber;
+
+extern "C" {
+
+int amber_mpn_abi_version(void) { return AMBER_MPN_ABI_VERSION; }
+const char* amber_mpn_last_error(void) { return g_last_error.c_str(); }
+
+int64_t amber_mpn_param_floats(const AmberMpnDesc* desc) {
+  if (validate(desc)) return -1;
+  return build_layout(*desc).n_params;
+}
+int64_t amber_mpn_packed_floats(const AmberMpnDesc* desc) {
+  if (validate(desc)) return -1;
+  const int64_t n = build_layout(*desc).n_packed;
+  return n > 0 ? n : 4;  // never hand out a zero-sized buffer
+}
+
+int amber_mpn_pack_weights(const AmberMpnDesc* desc, const float* params, float* packed, void* stream) {
+  int rc = validate(desc);
+  if (rc) return rc;
+  if (!params || !packed) return fail(AMBER_ERR_INVALID_ARGUMENT, "params / packed is NULL");
+  const Layout lay = build_layout(*desc);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int L = desc->latent;
+  auto pack_mlp = [&](const MlpLayout& m, int blocks0) -> hipError_t {
+    for (int l = 0; l < m.layers; ++l) {
+      if (l == 0) {
+        for (int cb = 0; cb < blocks0; ++cb)
+          if (m.PW[0][cb] >= 0) {
+            hipError_t e = launch_pack(L, params + m.W[0], m.in_cols, cb * L, packed + m.PW[0][cb], s);
+            if (e != hipSuccess) return e;
+          }
+      } else if (m.PW[l][0] >= 0) {
+        hipError_t e = launch_pack(L, params + m.W[l], L, 0, packed + m.PW[l][0], s);
+        if (e != hipSuccess) return e;
+      }
+    }
+    return hipSuccess;
+  };
+  HIP_TRY(pack_mlp(lay.node_embed, 0), "pack node embedding");
+  HIP_TRY(pack_mlp(lay.edge_embed, 0), "pack edge embedding");
+  for (int st = 0; st < desc->num_steps; ++st) {
+    HIP_TRY(pack_mlp(lay.edge[st], 3), "pack edge MLP");
+    HIP_TRY(pack_mlp(lay.node[st], 2), "pack node MLP");
+  }
+  if (desc->has_head) HIP_TRY(pack_mlp(lay.dec, 1), "pack decoder");
+  return AMBER_OK;
+}
+
+size_t amber_mpn_csr_workspace_bytes(int64_t num_nodes, int64_t num_edges) {
+  if (num_nodes < 0 || num_edges < 0) return 0;
+  return csr_workspace_bytes(num_nodes, num_edges) + 256;
+}
+
+int amber_mpn_csr_build(const int64_t* edge_index, int64_t num_edges, int64_t num_nodes, int32_t* rowptr, int32_t* src_sorted,
+                        int32_t* dst_sorted, int32_t* perm, int32_t* status, void* workspace, size_t workspace_bytes,
+                        void* stream) {
+  if (num_nodes < 0 || num_edges < 0 || num_nodes >= (1ll << 31) || num_edges >= (1ll << 31))
+    return fail(AMBER_ERR_INVALID_ARGUMENT, "num_nodes / num_edges out of int32 range");
+  if (!rowptr || !status || !workspace) return fail(AMBER_ERR_INVALID_ARGUMENT, "rowptr / status / workspace is NULL");
+  if (num_edges > 0 && (!edge_index || !src_sorted || !dst_sorted || !perm))
+    return fail(AMBER_ERR_INVALID_ARGUMENT, "edge arrays are NULL");
+  if (num_edges > 0 && num_nodes == 0) return fail(AMBER_ERR_INVALID_ARGUMENT, "edges without nodes");
+  if (workspace_bytes < amber_mpn_csr_workspace_bytes(num_nodes, num_edges))
+    return fail(AMBER_ERR_WORKSPACE_TOO_SMALL, "csr workspace %zu < %zu bytes", workspace_bytes,
+                amber_mpn_csr_workspace_bytes(num_nodes, num_edges));
+  // carve from a 256-byte aligned base
+  uintptr_t base = (reinterpret_cast<uintptr_t>(workspace) + 255) & ~static_cast<uintptr_t>(255);
+  HIP_TRY(csr_build(edge_index, num_edges, num_nodes, rowptr, src_sorted, dst_sorted, perm, status, reinterpret_cast<void*>(base),
+                    static_cast<hipStream_t>(stream)),
+          "csr_build");
+  return AMBER_OK;
+}
+
+int amber_mpn_segment_mean(const float* values_sorted, const int32_t* rowptr, int64_t num_nodes, int64_t num_edges, int32_t latent,
+                           float* out, void* stream) {
+  if (num_nodes < 0 || num_edges < 0) return fail(AMBER_ERR_INVALID_ARGUMENT, "negative size");
+  if (latent <= 0 || latent % 4 != 0 || latent > 1024) return fail(AMBER_ERR_UNSUPPORTED, "latent %d: need a multiple of 4, <= 1024", latent);
+  if (num_nodes > 0 && (!rowptr || !out)) return fail(AMBER_ERR_INVALID_ARGUMENT, "rowptr / out is NULL");
+  if (num_edges > 0 && !values_sorted) return fail(AMBER_ERR_INVALID_ARGUMENT, "values is NULL");
+  HIP_TRY(launch_segment_mean(values_sorted, rowptr, num_nodes, latent, out, static_cast<hipStream_t>(stream)), "segment_mean");
+  return AMBER_OK;
+}
+
+int amber_mpn_permute_rows(const float* in, const int32_t* perm, int64_t rows, int32_t width, int32_t gather, float* out,
+                           void* stream) {
+  if (rows < 0 || width <= 0 || width % 4 != 0) return fail(AMBER_ERR_INVALID_ARGUMENT, "bad rows / width");
+  if (rows > 0 && (!in || !perm || !out)) return fail(AMBER_ERR_INVALID_ARGUMENT, "NULL pointer");
+  HIP_TRY(launch_permute_rows(in, perm, rows, width, gather, out, static_cast<hipStream_t>(stream)), "permute_rows");
+  return AMBER_OK;
+}
+
+size_t amber_mpn_workspace_bytes(const AmberMpnDesc* desc, int64_t num_nodes, int64_t num_edges) {
+  if (validate(desc) || num_nodes < 0 || num_edges < 0) return 0;
+  return carve(*desc, num_nodes, num_edges, nullptr).bytes + 256;
+}
+
+static void* aligned_ws(void* workspace) {
+  return reinterpret_cast<void*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~static_cast<uintptr_t>(255));
+}
+
+int amber_mpn_embed(const AmberMpnDesc* desc, const float* params, const float* packed, int64_t num_nodes, int64_t num_edges,
+                    const float* x_raw, const float* edge_attr_raw, const int32_t* perm, float* x_latent, float* e_latent_sorted,
+                    void* workspace, size_t workspace_bytes, void* stream) {
+  (void)workspace;
+  (void)workspace_bytes;
+  int rc = validate(desc);
+  if (rc) return rc;
+  if (!params || !packed) return fail(AMBER_ERR_INVALID_ARGUMENT, "params / packed is NULL");
+  if (num_nodes > 0 && (!x_latent || (desc->in_node_features > 0 && !x_raw))) return fail(AMBER_ERR_INVALID_ARGUMENT, "node buffers NULL");
+  if (num_edges > 0 && (!e_latent_sorted || !perm || (desc->in_edge_features > 0 && !edge_attr_raw)))
+    return fail(AMBER_ERR_INVALID_ARGUMENT, "edge buffers NULL");
+  const Layout lay = build_layout(*desc);
+  Timer tm;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  rc = run_embedding(*desc, lay.node_embed, desc->in_node_features, params, packed, x_raw, num_nodes, nullptr, x_latent, s, tm);
+  if (rc) return rc;
+  return run_embedding(*desc, lay.edge_embed, desc->in_edge_features, params, packed, edge_attr_raw, num_edges, perm,
+                       e_latent_sorted, s, tm);
+}
+
+int amber_mpn_block(const AmberMpnDesc* desc, const float* params, const float* packed, int32_t step, int64_t num_nodes,
+                    int64_t num_edges, const int32_t* rowptr, const int32_t* src_sorted, const int32_t* dst_sorted, float* x_latent,
+                    float* e_latent_sorted, void* workspace, size_t workspace_bytes, void* stream) {
+  int rc = validate(desc);
+  if (rc) return rc;
+  if (step < 0 || step >= desc->num_steps) return fail(AMBER_ERR_INVALID_ARGUMENT, "step %d out of range", step);
+  if (!params || !packed || !workspace) return fail(AMBER_ERR_INVALID_ARGUMENT, "params / packed / workspace is NULL");
+  if (workspace_bytes < amber_mpn_workspace_bytes(desc, num_nodes, num_edges))
+    return fail(AMBER_ERR_WORKSPACE_TOO_SMALL, "workspace too small");
+  if (num_nodes == 0) return AMBER_OK;
+  if (!rowptr || !x_latent) return fail(AMBER_ERR_INVALID_ARGUMENT, "rowptr / x_latent is NULL");
+  if (num_edges > 0 && (!src_sorted || !dst_sorted || !e_latent_sorted)) return fail(AMBER_ERR_INVALID_ARGUMENT, "edge buffers NULL");
+  const Layout lay = build_layout(*desc);
+  const Workspace w = carve(*desc, num_nodes, num_edges, aligned_ws(workspace));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int L = desc->latent;
+  NodeArgs pa{};
+  pa.N = num_nodes;
+  pa.x_in = x_latent;
+  fill_node_proj(pa, lay, step, params, packed, w.Ps, w.Pd);
+  HIP_TRY(launch_node(L, pa, s), "node projection kernel");
+  EdgeArgs ea{};
+  ea.E = num_edges;
+  ea.N = num_nodes;
+  ea.src = src_sorted;
+  ea.dst = dst_sorted;
+  ea.rowptr = rowptr;
+  ea.e = e_latent_sorted;
+  ea.Ps = w.Ps;
+  ea.Pd = w.Pd;
+  fill_edge_step(ea, *desc, lay, step, params, packed);
+  ea.agg = w.agg;
+  ea.head = w.head;
+  ea.tail = w.tail;
+  ea.write_e = 1;
+  HIP_TRY(launch_edge(L, ea, s), "edge kernel");
+  NodeArgs na{};
+  na.N = num_nodes;
+  na.x_in = x_latent;
+  na.x_out = x_latent;
+  na.rowptr = rowptr;
+  na.agg = w.agg;
+  na.head = w.head;
+  na.tail = w.tail;
+  fill_node_update(na, *desc, lay, step, params, packed);
+  HIP_TRY(launch_node(L, na, s), "node kernel");
+  return AMBER_OK;
+}
+
+int amber_mpn_head(const AmberMpnDesc* desc, const float* params, const float* packed, int64_t num_nodes, const float* x_latent,
+                   const int32_t* out_index, float* out_sizing, void* stream) {
+  int rc = validate(desc);
+  if (rc) return rc;
+  if (!desc->has_head) return fail(AMBER_ERR_INVALID_ARGUMENT, "desc->has_head == 0");
+  if (!params || !packed) return fail(AMBER_ERR_INVALID_ARGUMENT, "params / packed is NULL");
+  if (num_nodes == 0) return AMBER_OK;
+  if (!x_latent || !out_sizing) return fail(AMBER_ERR_INVALID_ARGUMENT, "x_latent / out_sizing is NULL");
+  const Layout lay = build_layout(*desc);
+  NodeArgs a{};
+  a.N = num_nodes;
+  a.x_in = x_latent;
+  fill_node_head(a, *desc, lay, params, packed, out_index, out_sizing);
+  HIP_TRY(launch_node(desc->latent, a, static_cast<hipStream_t>(stream)), "head kernel");
+  return AMBER_OK;
+}
+
+int amber_mpn_forward(const AmberMpnDesc* desc, const float* params, const float* packed, int64_t num_nodes, int64_t num_edges,
+                      const float* x, const float* edge_attr, const int32_t* rowptr, const int32_t* src_sorted,
+                      const int32_t* dst_sorted, const int32_t* perm, const int32_t* out_index, float* out_node, float* out_edge,
+                      float* out_sizing, void* workspace, size_t workspace_bytes, void* stream) {
+  Timer tm;
+  return forward_impl(desc, params, packed, num_nodes, num_edges, x, edge_attr, rowptr, src_sorted, dst_sorted, perm, out_index,
+                      out_node, out_edge, out_sizing, workspace ? aligned_ws(workspace) : nullptr, workspace_bytes,
+                      static_cast<hipStream_t>(stream), tm);
+}
+
+int amber_mpn_forward_timed(const AmberMpnDesc* desc, const float* params, const float* packed, int64_t num_nodes,
+                            int64_t num_edges, const float* x, const float* edge_attr, const int32_t* rowptr,
+                            const int32_t* src_sorted, const int32_t* dst_sorted, const int32_t* perm, const int32_t* out_index,
+                            float* out_node, float* out_edge, float* out_sizing, void* workspace, size_t workspace_bytes,
+                            void* stream, float* kernel_ms, int32_t* kernel_launches) {
+  if (!kernel_ms) return fail(AMBER_ERR_INVALID_ARGUMENT, "kernel_ms is NULL");
+  Timer tm;
+  tm.on = true;
+  tm.s = static_cast<hipStream_t>(stream);
+  int rc = forward_impl(desc, params, packed, num_nodes, num_edges, x, edge_attr, rowptr, src_sorted, dst_sorted, perm, out_index,
+                        out_node, out_edge, out_sizing, workspace ? aligned_ws(workspace) : nullptr, workspace_bytes, tm.s, tm);
+  tm.collect(kernel_ms, kernel_launches);
+  return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,107 @@
+// Internal C++ interface between the host driver (api.hip) and the kernel translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/amber_mpn.h"
+
+namespace amber {
+
+constexpr int kTile = AMBER_MPN_TILE;  // sorted edges (or nodes) per wave tile
+constexpr int kMaxLayers = AMBER_MPN_MAX_MLP_LAYERS;
+
+// One dense layer of a chain: packed L x L weight (MFMA operand order), bias, optional post-activation norm.
+struct DenseLayer {
+  const float* w;     // packed, L*L floats
+  const float* b;     // [L]
+  const float* p;     // norm parameter 0 (gamma / scale) or nullptr
+  const float* q;     // norm parameter 1 (beta / shift) or nullptr
+};
+
+// Arguments of the fused edge kernel (K2-K6): one MessagePassingEdgeModule + residual + LayerNorm +
+// segmented sum over destinations.
+struct EdgeArgs {
+  int64_t E;
+  int64_t N;
+  const int32_t* src;     // [E] sorted
+  const int32_t* dst;     // [E] sorted
+  const int32_t* rowptr;  // [N+1]
+  const int32_t* perm;    // [E] or nullptr (only for out_edge)
+  float* e;               // [E,L] latent edge features, CSR order, updated in place
+  const float* Ps;        // [N,L]  W0[:, 0:L] x          (source part of the first layer)
+  const float* Pd;        // [N,L]  W0[:, L:2L] x + b0    (destination part + bias)
+  const float* w0e;       // packed W0[:, 2L:3L]
+  DenseLayer layers[kMaxLayers];  // layers[1..nl-1]
+  int32_t nl;
+  int32_t act;
+  int32_t residual;       // AMBER_MODE_*
+  int32_t layer_norm;     // AMBER_MODE_*
+  const float* gamma;
+  const float* beta;
+  float eps;
+  float* agg;             // [N,L] sums of rows that lie inside one tile
+  float* head;            // [T,L] partial sum of a tile's first row when that row began in an earlier tile
+  float* tail;            // [T,L] partial sum of a tile's last row when it began here and continues
+  int32_t write_e;        // store the updated e (CSR order)
+  float* out_edge;        // [E,L] edge_index order, or nullptr
+};
+
+// Arguments of the fused node kernel (K6 finish, K7, K8, next step's first-layer projections, K9, K10).
+struct NodeArgs {
+  int64_t N;
+  const float* x_in;      // [N,L]
+  float* x_out;           // [N,L] or nullptr (may alias x_in)
+  // update phase (MessagePassingNodeModule + residual + LayerNorm)
+  int32_t do_update;
+  const int32_t* rowptr;
+  const float* agg;
+  const float* head;
+  const float* tail;
+  const float* w0x;       // packed W0[:, 0:L]
+  const float* w0a;       // packed W0[:, L:2L]
+  const float* b0;
+  DenseLayer layers[kMaxLayers];  // layers[1..nl-1]
+  int32_t nl;
+  int32_t act;
+  int32_t residual;       // != NONE: add x_in
+  int32_t layer_norm;     // != NONE: LayerNorm(gamma, beta)
+  const float* gamma;
+  const float* beta;
+  float eps;
+  // projections for the next edge step
+  int32_t do_proj;
+  const float* w0s;       // packed next-step edge W0[:, 0:L]
+  const float* w0d;       // packed next-step edge W0[:, L:2L]
+  const float* b0e;       // next-step edge b0
+  float* Ps;
+  float* Pd;
+  // dense chain (decoder MLP or embedding MLP tail)
+  int32_t n_dense;
+  DenseLayer dense[kMaxLayers];
+  int32_t dense_act;
+  int32_t dense_norm;     // AMBER_NORM_*
+  float* dense_out;       // [N,L] or nullptr
+  // readout Linear(L,1)
+  int32_t do_readout;
+  const float* wr;        // [L]
+  const float* br;        // [1]
+  const int32_t* out_index;  // [N] or nullptr
+  float* out;
+};
+
+hipError_t launch_edge(int L, const EdgeArgs& a, hipStream_t s);
+hipError_t launch_node(int L, const NodeArgs& a, hipStream_t s);
+// out[r] = act(W in[idx(r)] + b): small-K linear (K = F >= 0), idx = perm gather or identity
+hipError_t launch_embed(int L, const float* in, int64_t rows, int F, const float* W, const float* b, const int32_t* perm,
+                        int act_or_neg1, float* out, hipStream_t s);
+// re-tile W[L, ld] columns [col0, col0+L) into MFMA operand order
+hipError_t launch_pack(int L, const float* W, int ld, int col0, float* out, hipStream_t s);
+hipError_t launch_segment_mean(const float* vals, const int32_t* rowptr, int64_t N, int L, float* out, hipStream_t s);
+hipError_t launch_permute_rows(const float* in, const int32_t* perm, int64_t rows, int width, int gather, float* out,
+                               hipStream_t s);
+
+size_t csr_workspace_bytes(int64_t N, int64_t E);
+hipError_t csr_build(const int64_t* edge_index, int64_t E, int64_t N, int32_t* rowptr, int32_t* src_sorted,
+                     int32_t* dst_sorted, int32_t* perm, int32_t* status, void* ws, hipStream_t s);
+
+}  // namespace amber

@@ -1,0 +1,665 @@
+// Hand-written gfx950 (CDNA4, wave64) kernels for AMBER's message-passing network forward path.
+//
+// Data layout of a wave tile
+// --------------------------
+// Every wave owns a tile of 32 rows (edges in CSR order, or nodes) x L latent features, held TRANSPOSED
+// in MFMA accumulator layout: with c = lane & 31 (row of the tile) and h = lane >> 5, lane (h, c) holds
+// the 16-byte chunks  X[c][8j + 4h .. 8j + 4h + 3],  j = 0 .. L/8-1  (so the two half-waves split each row).
+// This is at once
+//   * what a lane gets by loading 16-byte pieces of its own row from memory,
+//   * the C/D layout of v_mfma_f32_32x32x2_f32 when the weights are the A operand (output feature on the
+//     MFMA row) and the tile is the B operand (tile row on the MFMA column):
+//         acc[fb][i]  <->  feature 32 fb + (i & 3) + 8 (i >> 2) + 4 h  =  chunk j = 4 fb + (i >> 2), element i & 3,
+//   * a valid B operand of the NEXT layer's MFMAs with no data movement: k-step (j, t) contracts over
+//     k = 8j + 4h + t in half-wave h, and the weights are pre-tiled (pack_kernel) to match.
+// So a whole MLP (edge: W0e e + P_s[src] + P_d[dst] -> act -> W1 -> act -> +residual -> LayerNorm) runs
+// inside one wave's registers; LayerNorm needs one cross-half shuffle per row.
+//
+// The first layer of the edge MLP is split by columns (W0 [x_s | x_d | e] = W0s x_s + W0d x_d + W0e e): the
+// node kernel computes P_s = W0s x and P_d = W0d x + b0 once per node and the edge kernel gathers them.
+//
+// Aggregation (scatter_mean) is fused into the edge kernel: the tile is staged in LDS and summed
+// sequentially per destination row in CSR order (deterministic, no atomics).  Rows cut by a tile
+// boundary leave partial sums in head/tail buffers that the node kernel adds in tile order.
+#include "mpn_internal.h"
+
+namespace amber {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#define DEVINL __device__ __forceinline__
+
+constexpr int kWavesPerBlock = 4;
+constexpr int kBlock = 64 * kWavesPerBlock;
+
+template <int L>
+struct Tile {
+  f32x16 a[L / 32];
+};
+
+template <int L>
+constexpr int stage_stride() {
+  return L + 4;  // floats; +16 B per row keeps 16-byte alignment and spreads rows over LDS banks
+}
+template <int L>
+constexpr int stage_floats() {
+  return kTile * stage_stride<L>();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// activations (torch defaults)
+// ---------------------------------------------------------------------------------------------------
+DEVINL float act_one(float v, int act) {
+  switch (act) {
+    case AMBER_ACT_RELU:
+      return v > 0.f ? v : 0.f;
+    case AMBER_ACT_LEAKYRELU:
+      return v > 0.f ? v : 0.01f * v;
+    case AMBER_ACT_TANH:
+      return tanhf(v);
+    case AMBER_ACT_ELU:
+      return v > 0.f ? v : expm1f(v);
+    case AMBER_ACT_SILU:
+      return v / (1.f + expf(-v));
+    case AMBER_ACT_MISH: {
+      const float sp = v > 20.f ? v : log1pf(expf(v));  // softplus, threshold 20
+      return v * tanhf(sp);
+    }
+    case AMBER_ACT_GELU:
+      return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+    default:
+      return v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// tile helpers (all loops fully unrolled: register indices must be compile-time constants)
+// ---------------------------------------------------------------------------------------------------
+template <int L>
+DEVINL void tile_set_chunk(Tile<L>& t, int j, f32x4 v) {
+  t.a[j >> 2][(j & 3) * 4 + 0] = v[0];
+  t.a[j >> 2][(j & 3) * 4 + 1] = v[1];
+  t.a[j >> 2][(j & 3) * 4 + 2] = v[2];
+  t.a[j >> 2][(j & 3) * 4 + 3] = v[3];
+}
+template <int L>
+DEVINL f32x4 tile_get_chunk(const Tile<L>& t, int j) {
+  f32x4 v;
+  v[0] = t.a[j >> 2][(j & 3) * 4 + 0];
+  v[1] = t.a[j >> 2][(j & 3) * 4 + 1];
+  v[2] = t.a[j >> 2][(j & 3) * 4 + 2];
+  v[3] = t.a[j >> 2][(j & 3) * 4 + 3];
+  return v;
+}
+
+template <int L>
+DEVINL void tile_zero(Tile<L>& t) {
+#pragma unroll
+  for (int fb = 0; fb < L / 32; ++fb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t.a[fb][i] = 0.f;
+}
+
+// t = rows[row][:]  (this lane's chunks of one row-major row of L floats)
+template <int L>
+DEVINL void tile_load_row(Tile<L>& t, const float* __restrict__ base, int64_t row, int h) {
+  const f32x4* p = reinterpret_cast<const f32x4*>(base + row * L) + h;
+#pragma unroll
+  for (int j = 0; j < L / 8; ++j) tile_set_chunk<L>(t, j, p[2 * j]);
+}
+template <int L>
+DEVINL void tile_add_row(Tile<L>& t, const float* __restrict__ base, int64_t row, int h) {
+  const f32x4* p = reinterpret_cast<const f32x4*>(base + row * L) + h;
+#pragma unroll
+  for (int j = 0; j < L / 8; ++j) tile_set_chunk<L>(t, j, tile_get_chunk<L>(t, j) + p[2 * j]);
+}
+// t[c][f] = vec[f] for every row (bias as initial accumulator)
+template <int L>
+DEVINL void tile_load_vec(Tile<L>& t, const float* __restrict__ vec, int h) {
+  const f32x4* p = reinterpret_cast<const f32x4*>(vec) + h;
+#pragma unroll
+  for (int j = 0; j < L / 8; ++j) tile_set_chunk<L>(t, j, p[2 * j]);
+}
+template <int L>
+DEVINL void tile_add(Tile<L>& t, const Tile<L>& o) {
+#pragma unroll
+  for (int fb = 0; fb < L / 32; ++fb) t.a[fb] += o.a[fb];
+}
+
+// acc += W * in, W an L x L matrix pre-tiled by pack_kernel; exact fp32 MFMA (a k-ordered fmaf chain).
+template <int L>
+DEVINL void tile_gemm(Tile<L>& acc, const float* __restrict__ wpacked, const Tile<L>& in, int lane) {
+  constexpr int NFB = L / 32, NJ = L / 8;
+  const f32x4* __restrict__ w = reinterpret_cast<const f32x4*>(wpacked) + lane;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    f32x4 wf[NFB];
+#pragma unroll
+    for (int fb = 0; fb < NFB; ++fb) wf[fb] = w[(j * NFB + fb) * 64];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const float b = in.a[j >> 2][(j & 3) * 4 + t];
+#pragma unroll
+      for (int fb = 0; fb < NFB; ++fb) acc.a[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[fb][t], b, acc.a[fb], 0, 0, 0);
+    }
+  }
+}
+
+// LayerNorm over the L features of every row: the row lives in lanes (0, c) and (1, c).
+template <int L>
+DEVINL void tile_layernorm(Tile<L>& t, const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int h) {
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+  for (int fb = 0; fb < L / 32; ++fb)
+#pragma unroll
+    for (int i = 0; i < 16; i += 4) {
+      s0 += t.a[fb][i + 0];
+      s1 += t.a[fb][i + 1];
+      s2 += t.a[fb][i + 2];
+      s3 += t.a[fb][i + 3];
+    }
+  float s = (s0 + s1) + (s2 + s3);
+  s += __shfl_xor(s, 32);
+  const float mean = s * (1.0f / L);
+  s0 = s1 = s2 = s3 = 0.f;
+#pragma unroll
+  for (int fb = 0; fb < L / 32; ++fb)
+#pragma unroll
+    for (int i = 0; i < 16; i += 4) {
+      const float d0 = t.a[fb][i + 0] - mean, d1 = t.a[fb][i + 1] - mean;
+      const float d2 = t.a[fb][i + 2] - mean, d3 = t.a[fb][i + 3] - mean;
+      s0 += d0 * d0;
+      s1 += d1 * d1;
+      s2 += d2 * d2;
+      s3 += d3 * d3;
+    }
+  float q = (s0 + s1) + (s2 + s3);
+  q += __shfl_xor(q, 32);
+  const float rstd = 1.0f / sqrtf(q * (1.0f / L) + eps);
+  const f32x4* g = reinterpret_cast<const f32x4*>(gamma) + h;
+  const f32x4* b = reinterpret_cast<const f32x4*>(beta) + h;
+#pragma unroll
+  for (int j = 0; j < L / 8; ++j) {
+    const f32x4 v = tile_get_chunk<L>(t, j);
+    tile_set_chunk<L>(t, j, (v - mean) * rstd * g[2 * j] + b[2 * j]);
+  }
+}
+// per-feature affine v * p + q (eval-mode BatchNorm folded on the host)
+template <int L>
+DEVINL void tile_affine(Tile<L>& t, const float* __restrict__ p, const float* __restrict__ q, int h) {
+  const f32x4* g = reinterpret_cast<const f32x4*>(p) + h;
+  const f32x4* b = reinterpret_cast<const f32x4*>(q) + h;
+#pragma unroll
+  for (int j = 0; j < L / 8; ++j) tile_set_chunk<L>(t, j, tile_get_chunk<L>(t, j) * g[2 * j] + b[2 * j]);
+}
+
+// tile <-> LDS staging area of the wave, row-major [32][L + 4]
+template <int L>
+DEVINL void tile_stage(float* stage, const Tile<L>& t, int c, int h) {
+  f32x4* p = reinterpret_cast<f32x4*>(stage + c * stage_stride<L>()) + h;
+#pragma unroll
+  for (int j = 0; j < L / 8; ++j) p[2 * j] = tile_get_chunk<L>(t, j);
+}
+template <int L>
+DEVINL void tile_unstage(const float* stage, Tile<L>& t, int c, int h) {
+  const f32x4* p = reinterpret_cast<const f32x4*>(stage + c * stage_stride<L>()) + h;
+#pragma unroll
+  for (int j = 0; j < L / 8; ++j) tile_set_chunk<L>(t, j, p[2 * j]);
+}
+
+// Activation on a tile.  relu / leakyrelu stay in registers; the transcendental ones take a round trip
+// through the wave's LDS staging area so that each math routine is instantiated once (block-uniform branch).
+template <int L>
+DEVINL void tile_act(Tile<L>& t, int act, float* stage, int lane) {
+  if (act == AMBER_ACT_RELU) {
+#pragma unroll
+    for (int fb = 0; fb < L / 32; ++fb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) t.a[fb][i] = fmaxf(t.a[fb][i], 0.f);
+  } else if (act == AMBER_ACT_LEAKYRELU) {
+#pragma unroll
+    for (int fb = 0; fb < L / 32; ++fb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float v = t.a[fb][i];
+        t.a[fb][i] = v > 0.f ? v : 0.01f * v;
+      }
+  } else {
+    const int c = lane & 31, h = lane >> 5;
+    __syncthreads();
+    tile_stage<L>(stage, t, c, h);
+    __syncthreads();
+    for (int i = lane; i < stage_floats<L>(); i += 64) stage[i] = act_one(stage[i], act);
+    __syncthreads();
+    tile_unstage<L>(stage, t, c, h);
+  }
+}
+
+// Store the staged tile as whole rows: out[row(r)][:] = stage[r][:], r < nvalid.  rowmap == nullptr: rows
+// row0 + r; otherwise rows rowmap[row0 + r] (un-permute to edge_index order).
+template <int L>
+DEVINL void stage_store_rows(const float* stage, float* __restrict__ out, int64_t row0, int nvalid,
+                             const int32_t* __restrict__ rowmap, int lane) {
+  constexpr int LPR = L / 4;        // lanes per row (16 B each)
+  constexpr int RPI = 64 / LPR;     // rows per wave instruction
+  const int q = lane % LPR;
+#pragma unroll
+  for (int it = 0; it < kTile / RPI; ++it) {
+    const int r = it * RPI + lane / LPR;
+    if (r < nvalid) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(stage + r * stage_stride<L>() + 4 * q);
+      const int64_t dr = rowmap ? static_cast<int64_t>(rowmap[row0 + r]) : row0 + r;
+      *reinterpret_cast<f32x4*>(out + dr * L + 4 * q) = v;
+    }
+  }
+}
+
+// XCD-aware block remap: blocks b and b + 8 share an XCD (round-robin dispatch), so give each XCD a
+// contiguous range of tiles; neighbouring tiles gather overlapping P_s rows and then share an L2.
+DEVINL int64_t xcd_remap(int64_t bid, int64_t nblk) {
+  const int64_t xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// edge kernel: K2 (gather), K3 (edge MLP), K4 (residual), K5 (LayerNorm), K6 (segmented sum)
+// reference: MessagePassingEdgeModule.forward (src/mpn/message_passing_modules.py:38-52),
+//            MessagePassingBlock.forward (src/mpn/message_passing_block.py:117-121,127-128),
+//            scatter_mean call (message_passing_modules.py:68)
+// ---------------------------------------------------------------------------------------------------
+template <int L>
+__global__ __launch_bounds__(kBlock) void edge_kernel(const EdgeArgs a, const int64_t nblk) {
+  __shared__ __attribute__((aligned(16))) float stage_all[kWavesPerBlock * stage_floats<L>()];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & 31, h = lane >> 5;
+  float* stage = stage_all + wave * stage_floats<L>();
+
+  const int64_t tile = xcd_remap(blockIdx.x, nblk) * kWavesPerBlock + wave;
+  const int64_t p0 = tile * kTile;
+  int nvalid = 0;
+  if (p0 < a.E) nvalid = (a.E - p0) < kTile ? static_cast<int>(a.E - p0) : kTile;
+  int64_t p = p0 + c;
+  if (p > a.E - 1) p = a.E - 1;  // clamp: out-of-range lanes recompute the last edge and store nothing
+  const int s = a.src[p], d = a.dst[p];
+
+  Tile<L> ein;
+  tile_load_row<L>(ein, a.e, p, h);
+  Tile<L> acc;
+  tile_load_row<L>(acc, a.Ps, s, h);
+  tile_add_row<L>(acc, a.Pd, d, h);
+  tile_gemm<L>(acc, a.w0e, ein, lane);
+  tile_act<L>(acc, a.act, stage, lane);
+#pragma unroll 1
+  for (int l = 1; l < a.nl; ++l) {
+    Tile<L> nxt;
+    tile_load_vec<L>(nxt, a.layers[l].b, h);
+    tile_gemm<L>(nxt, a.layers[l].w, acc, lane);
+    tile_act<L>(nxt, a.act, stage, lane);
+    acc = nxt;
+  }
+  if (a.residual == AMBER_MODE_INNER) tile_add<L>(acc, ein);
+  if (a.layer_norm == AMBER_MODE_INNER) tile_layernorm<L>(acc, a.gamma, a.beta, a.eps, h);
+
+  // ---- the node module aggregates THESE values (message_passing_block.py:119-123) ----
+  __syncthreads();
+  tile_stage<L>(stage, acc, c, h);
+  __syncthreads();
+  if (nvalid > 0) {
+    constexpr int FPL = (L + 63) / 64;  // features per lane in the reduction
+    const bool active = lane * FPL < L;
+    const int fo = active ? lane * FPL : 0;
+    int cur = __builtin_amdgcn_readlane(d, 0);
+    bool started_before = p0 > static_cast<int64_t>(a.rowptr[cur]);
+    float sum[FPL];
+#pragma unroll
+    for (int qf = 0; qf < FPL; ++qf) sum[qf] = 0.f;
+    for (int cc = 0; cc <= nvalid; ++cc) {
+      const int dc = cc < nvalid ? __builtin_amdgcn_readlane(d, cc) : -1;
+      if (dc != cur) {
+        // row `cur` ends at sorted position p0 + cc (exclusive) within this tile, or the tile ends
+        const bool ends_here = cc < nvalid || (p0 + nvalid) == static_cast<int64_t>(a.rowptr[cur + 1]);
+        float* dstp;
+        if (!started_before && ends_here)
+          dstp = a.agg + static_cast<int64_t>(cur) * L;
+        else if (started_before)
+          dstp = a.head + tile * L;
+        else
+          dstp = a.tail + tile * L;
+        if (active) {
+#pragma unroll
+          for (int qf = 0; qf < FPL; ++qf) dstp[fo + qf] = sum[qf];
+        }
+        cur = dc;
+        started_before = false;
+#pragma unroll
+        for (int qf = 0; qf < FPL; ++qf) sum[qf] = 0.f;
+      }
+      if (cc < nvalid) {
+#pragma unroll
+        for (int qf = 0; qf < FPL; ++qf) sum[qf] += stage[cc * stage_stride<L>() + fo + qf];
+      }
+    }
+  }
+  const bool outer = a.residual == AMBER_MODE_OUTER || a.layer_norm == AMBER_MODE_OUTER;
+  if (outer) {
+    if (a.residual == AMBER_MODE_OUTER) tile_add<L>(acc, ein);
+    if (a.layer_norm == AMBER_MODE_OUTER) tile_layernorm<L>(acc, a.gamma, a.beta, a.eps, h);
+    __syncthreads();
+    tile_stage<L>(stage, acc, c, h);
+    __syncthreads();
+  }
+  if (a.write_e) stage_store_rows<L>(stage, a.e, p0, nvalid, nullptr, lane);
+  if (a.out_edge) stage_store_rows<L>(stage, a.out_edge, p0, nvalid, a.perm, lane);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// node kernel: finish K6 (combine partial sums, divide by in-degree), K7 (node MLP), K8 (residual + LN),
+// the next edge step's first-layer projections P_s / P_d, and optionally K9/K10 (decoder + readout).
+// reference: MessagePassingNodeModule.forward (src/mpn/message_passing_modules.py:61-72),
+//            MessagePassingBlock.forward (message_passing_block.py:123-128),
+//            SupervisedMPN.forward (src/algorithm/architecture/supervised_mpn.py:51-54), MLP (mlp.py:60-95)
+// Also used as a generic row-wise dense chain (embedding MLP tail).
+// ---------------------------------------------------------------------------------------------------
+template <int L>
+__global__ __launch_bounds__(kBlock) void node_kernel(const NodeArgs a, const int64_t nblk) {
+  __shared__ __attribute__((aligned(16))) float stage_all[kWavesPerBlock * stage_floats<L>()];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & 31, h = lane >> 5;
+  float* stage = stage_all + wave * stage_floats<L>();
+
+  const int64_t tile = xcd_remap(blockIdx.x, nblk) * kWavesPerBlock + wave;
+  const int64_t n0 = tile * kTile;
+  int nvalid = 0;
+  if (n0 < a.N) nvalid = (a.N - n0) < kTile ? static_cast<int>(a.N - n0) : kTile;
+  int64_t n = n0 + c;
+  if (n > a.N - 1) n = a.N - 1;
+
+  Tile<L> v;
+  tile_load_row<L>(v, a.x_in, n, h);
+
+  if (a.do_update) {
+    // mean of the incoming (updated) edge features; zero in-degree -> 0 (scatter_mean semantics)
+    Tile<L> g;
+    const int r0 = a.rowptr[n], r1 = a.rowptr[n + 1];
+    const int deg = r1 - r0;
+    if (deg == 0) {
+      tile_zero<L>(g);
+    } else {
+      const int t0 = r0 / kTile, t1 = (r1 - 1) / kTile;
+      if (t0 == t1) {
+        tile_load_row<L>(g, a.agg, n, h);
+      } else {
+        // the row was cut by tile boundaries: tail of its first tile, then heads, in tile order
+        tile_load_row<L>(g, a.tail, t0, h);
+        for (int t = t0 + 1; t <= t1; ++t) tile_add_row<L>(g, a.head, t, h);
+      }
+      const float degf = static_cast<float>(deg);
+#pragma unroll
+      for (int fb = 0; fb < L / 32; ++fb) g.a[fb] = g.a[fb] / degf;
+    }
+    Tile<L> acc;
+    tile_load_vec<L>(acc, a.b0, h);
+    tile_gemm<L>(acc, a.w0x, v, lane);
+    tile_gemm<L>(acc, a.w0a, g, lane);
+    tile_act<L>(acc, a.act, stage, lane);
+#pragma unroll 1
+    for (int l = 1; l < a.nl; ++l) {
+      Tile<L> nxt;
+      tile_load_vec<L>(nxt, a.layers[l].b, h);
+      tile_gemm<L>(nxt, a.layers[l].w, acc, lane);
+      tile_act<L>(nxt, a.act, stage, lane);
+      acc = nxt;
+    }
+    // inner and outer placement coincide for nodes: nothing reads x between them (block.py:124-128)
+    if (a.residual != AMBER_MODE_NONE) tile_add<L>(acc, v);
+    if (a.layer_norm != AMBER_MODE_NONE) tile_layernorm<L>(acc, a.gamma, a.beta, a.eps, h);
+    v = acc;
+  }
+  if (a.x_out) {
+    __syncthreads();
+    tile_stage<L>(stage, v, c, h);
+    __syncthreads();
+    stage_store_rows<L>(stage, a.x_out, n0, nvalid, nullptr, lane);
+  }
+  if (a.do_proj) {
+    Tile<L> acc;
+    tile_zero<L>(acc);
+    tile_gemm<L>(acc, a.w0s, v, lane);
+    __syncthreads();
+    tile_stage<L>(stage, acc, c, h);
+    __syncthreads();
+    stage_store_rows<L>(stage, a.Ps, n0, nvalid, nullptr, lane);
+    tile_load_vec<L>(acc, a.b0e, h);
+    tile_gemm<L>(acc, a.w0d, v, lane);
+    __syncthreads();
+    tile_stage<L>(stage, acc, c, h);
+    __syncthreads();
+    stage_store_rows<L>(stage, a.Pd, n0, nvalid, nullptr, lane);
+  }
+  if (a.n_dense > 0) {
+#pragma unroll 1
+    for (int l = 0; l < a.n_dense; ++l) {
+      Tile<L> nxt;
+      tile_load_vec<L>(nxt, a.dense[l].b, h);
+      tile_gemm<L>(nxt, a.dense[l].w, v, lane);
+      tile_act<L>(nxt, a.dense_act, stage, lane);
+      if (a.dense_norm == AMBER_NORM_LAYER)
+        tile_layernorm<L>(nxt, a.dense[l].p, a.dense[l].q, 1e-5f, h);
+      else if (a.dense_norm == AMBER_NORM_AFFINE)
+        tile_affine<L>(nxt, a.dense[l].p, a.dense[l].q, h);
+      v = nxt;
+    }
+    if (a.dense_out) {
+      __syncthreads();
+      tile_stage<L>(stage, v, c, h);
+      __syncthreads();
+      stage_store_rows<L>(stage, a.dense_out, n0, nvalid, nullptr, lane);
+    }
+  }
+  if (a.do_readout) {
+    const f32x4* w = reinterpret_cast<const f32x4*>(a.wr) + h;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+    for (int j = 0; j < L / 8; ++j) {
+      const f32x4 x = tile_get_chunk<L>(v, j);
+      const f32x4 ww = w[2 * j];
+      s0 += x[0] * ww[0];
+      s1 += x[1] * ww[1];
+      s2 += x[2] * ww[2];
+      s3 += x[3] * ww[3];
+    }
+    float s = (s0 + s1) + (s2 + s3);
+    s += __shfl_xor(s, 32);
+    s += a.br[0];
+    if (h == 0 && c < nvalid) {
+      const int64_t oi = a.out_index ? static_cast<int64_t>(a.out_index[n]) : n;
+      if (oi >= 0) a.out[oi] = s;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K0 / K1: input embeddings with a small contraction (F raw features): out[r] = act(W in[idx(r)] + b).
+// reference: Embedding.forward (src/mpn/common/embedding.py:44-54), EmptyLinear (empty_linear_layer.py:44-45)
+// One thread per (row, 4 output features); W^T staged in LDS.  HBM-write bound.
+// ---------------------------------------------------------------------------------------------------
+template <int L>
+__global__ __launch_bounds__(256) void embed_kernel(const float* __restrict__ in, int64_t rows, int F,
+                                                    const float* __restrict__ W, const float* __restrict__ b,
+                                                    const int32_t* __restrict__ perm, int act, float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float wt[];  // [F][L]
+  for (int i = threadIdx.x; i < F * L; i += blockDim.x) {
+    const int f = i / F, k = i % F;  // W is [L, F] row-major
+    wt[k * L + f] = W[i];
+  }
+  __syncthreads();
+  constexpr int LPR = L / 4;
+  constexpr int RPB = 256 / LPR;
+  const int q = threadIdx.x % LPR;
+  const f32x4 bias = reinterpret_cast<const f32x4*>(b)[q];
+  for (int64_t r = static_cast<int64_t>(blockIdx.x) * RPB + threadIdx.x / LPR; r < rows;
+       r += static_cast<int64_t>(gridDim.x) * RPB) {
+    const int64_t sr = perm ? static_cast<int64_t>(perm[r]) : r;
+    f32x4 acc = bias;
+    for (int k = 0; k < F; ++k) {
+      const float xv = in[sr * F + k];
+      acc += xv * reinterpret_cast<const f32x4*>(wt + k * L)[q];
+    }
+    if (act >= 0) {
+      acc[0] = act_one(acc[0], act);
+      acc[1] = act_one(acc[1], act);
+      acc[2] = act_one(acc[2], act);
+      acc[3] = act_one(acc[3], act);
+    }
+    reinterpret_cast<f32x4*>(out + r * L)[q] = acc;
+  }
+}
+
+// Re-tile columns [col0, col0 + L) of W[L, ld] into MFMA operand order:
+// out[((j * L/32 + fb) * 64 + lane) * 4 + t] = W[32 fb + (lane & 31)][col0 + 8 j + 4 (lane >> 5) + t]
+template <int L>
+__global__ void pack_kernel(const float* __restrict__ W, int ld, int col0, float* __restrict__ out) {
+  constexpr int NFB = L / 32;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // float4 index
+  if (i >= L * L / 4) return;
+  const int lane = i & 63, fb = (i >> 6) % NFB, j = (i >> 6) / NFB;
+  const float* src = W + static_cast<int64_t>(32 * fb + (lane & 31)) * ld + col0 + 8 * j + 4 * (lane >> 5);
+  f32x4 v;
+  v[0] = src[0];
+  v[1] = src[1];
+  v[2] = src[2];
+  v[3] = src[3];
+  reinterpret_cast<f32x4*>(out)[i] = v;
+}
+
+// Stand-alone K6: deterministic CSR segmented mean (thread per (row, 16-byte feature chunk), summed in row order).
+__global__ void segment_mean_kernel(const float* __restrict__ vals, const int32_t* __restrict__ rowptr, int64_t N,
+                                    int L, float* __restrict__ out) {
+  const int lpr = L / 4;
+  const int64_t total = N * lpr;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total;
+       i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const int64_t n = i / lpr;
+    const int q = static_cast<int>(i % lpr);
+    const int r0 = rowptr[n], r1 = rowptr[n + 1];
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int p = r0; p < r1; ++p) s += reinterpret_cast<const f32x4*>(vals + static_cast<int64_t>(p) * L)[q];
+    const float cnt = static_cast<float>(r1 - r0 > 1 ? r1 - r0 : 1);
+    reinterpret_cast<f32x4*>(out + n * L)[q] = s / cnt;
+  }
+}
+
+__global__ void permute_rows_kernel(const float* __restrict__ in, const int32_t* __restrict__ perm, int64_t rows,
+                                    int width, int gather, float* __restrict__ out) {
+  const int lpr = width / 4;
+  const int64_t total = rows * lpr;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total;
+       i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const int64_t r = i / lpr;
+    const int q = static_cast<int>(i % lpr);
+    const int64_t o = perm[r];
+    const int64_t sr = gather ? o : r, dr = gather ? r : o;
+    reinterpret_cast<f32x4*>(out + dr * width)[q] = reinterpret_cast<const f32x4*>(in + sr * width)[q];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------------
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+template <int L>
+static hipError_t launch_edge_t(const EdgeArgs& a, hipStream_t s) {
+  const int64_t nblk = cdiv(cdiv(a.E, kTile), kWavesPerBlock);
+  if (nblk == 0) return hipSuccess;
+  hipLaunchKernelGGL(edge_kernel<L>, dim3(static_cast<unsigned>(nblk)), dim3(kBlock), 0, s, a, nblk);
+  return hipGetLastError();
+}
+template <int L>
+static hipError_t launch_node_t(const NodeArgs& a, hipStream_t s) {
+  const int64_t nblk = cdiv(cdiv(a.N, kTile), kWavesPerBlock);
+  if (nblk == 0) return hipSuccess;
+  hipLaunchKernelGGL(node_kernel<L>, dim3(static_cast<unsigned>(nblk)), dim3(kBlock), 0, s, a, nblk);
+  return hipGetLastError();
+}
+template <int L>
+static hipError_t launch_embed_t(const float* in, int64_t rows, int F, const float* W, const float* b,
+                                 const int32_t* perm, int act, float* out, hipStream_t s) {
+  if (rows == 0) return hipSuccess;
+  constexpr int RPB = 256 / (L / 4);
+  int64_t grid = cdiv(rows, RPB);
+  if (grid > 256 * 16) grid = 256 * 16;
+  hipLaunchKernelGGL(embed_kernel<L>, dim3(static_cast<unsigned>(grid)), dim3(256), static_cast<size_t>(F) * L * sizeof(float),
+                     s, in, rows, F, W, b, perm, act, out);
+  return hipGetLastError();
+}
+template <int L>
+static hipError_t launch_pack_t(const float* W, int ld, int col0, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(pack_kernel<L>, dim3(cdiv(L * L / 4, 256)), dim3(256), 0, s, W, ld, col0, out);
+  return hipGetLastError();
+}
+
+#define AMBER_DISPATCH_L(L, CALL)       \
+  switch (L) {                          \
+    case 32:                            \
+      return CALL<32>;                  \
+    case 64:                            \
+      return CALL<64>;                  \
+    case 128:                           \
+      return CALL<128>;                 \
+    default:                            \
+      return hipErrorInvalidValue;      \
+  }
+
+hipError_t launch_edge(int L, const EdgeArgs& a, hipStream_t s) {
+  switch (L) {
+    case 32: return launch_edge_t<32>(a, s);
+    case 64: return launch_edge_t<64>(a, s);
+    case 128: return launch_edge_t<128>(a, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+hipError_t launch_node(int L, const NodeArgs& a, hipStream_t s) {
+  switch (L) {
+    case 32: return launch_node_t<32>(a, s);
+    case 64: return launch_node_t<64>(a, s);
+    case 128: return launch_node_t<128>(a, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+hipError_t launch_embed(int L, const float* in, int64_t rows, int F, const float* W, const float* b, const int32_t* perm,
+                        int act, float* out, hipStream_t s) {
+  switch (L) {
+    case 32: return launch_embed_t<32>(in, rows, F, W, b, perm, act, out, s);
+    case 64: return launch_embed_t<64>(in, rows, F, W, b, perm, act, out, s);
+    case 128: return launch_embed_t<128>(in, rows, F, W, b, perm, act, out, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+hipError_t launch_pack(int L, const float* W, int ld, int col0, float* out, hipStream_t s) {
+  switch (L) {
+    case 32: return launch_pack_t<32>(W, ld, col0, out, s);
+    case 64: return launch_pack_t<64>(W, ld, col0, out, s);
+    case 128: return launch_pack_t<128>(W, ld, col0, out, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+hipError_t launch_segment_mean(const float* vals, const int32_t* rowptr, int64_t N, int L, float* out, hipStream_t s) {
+  if (N == 0) return hipSuccess;
+  int64_t grid = cdiv(N * (L / 4), 256);
+  if (grid > 256 * 32) grid = 256 * 32;
+  hipLaunchKernelGGL(segment_mean_kernel, dim3(static_cast<unsigned>(grid)), dim3(256), 0, s, vals, rowptr, N, L, out);
+  return hipGetLastError();
+}
+hipError_t launch_permute_rows(const float* in, const int32_t* perm, int64_t rows, int width, int gather, float* out,
+                               hipStream_t s) {
+  if (rows == 0) return hipSuccess;
+  int64_t grid = cdiv(rows * (width / 4), 256);
+  if (grid > 256 * 32) grid = 256 * 32;
+  hipLaunchKernelGGL(permute_rows_kernel, dim3(static_cast<unsigned>(grid)), dim3(256), 0, s, in, perm, rows, width, gather, out);
+  return hipGetLastError();
+}
+
+}  // namespace amber

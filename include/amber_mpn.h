@@ -1,0 +1,193 @@
+/*
+ * amber_mpn.h -- C ABI of libamber_mpn.so: AMBER's message-passing-network forward path on MI355X (gfx950).
+ *
+ * The reference (NiklasFreymuth/AMBER) is 100 % Python and has no FFI of its own; each entry point below
+ * replaces the torch / torch_scatter code of the reference function it cites (paths relative to the
+ * reference root).  INTEGRATION.md shows the ctypes binding a maintainer adds on the reference side.
+ *
+ * Conventions
+ *   - Every pointer is a DEVICE pointer unless a comment says "host".  The caller owns every buffer
+ *     (inputs, outputs, workspace); the library allocates nothing and keeps no state between calls.
+ *   - All floating point data is fp32, row-major; indices handed in are int64 (torch edge_index), the
+ *     CSR the library builds and consumes is int32.
+ *   - `stream` is a hipStream_t passed as void* (0 = default stream).  All work is enqueued on it; no
+ *     call synchronises the device.
+ *   - Return value: 0 on success, negative AMBER_ERR_* otherwise; amber_mpn_last_error() returns a
+ *     thread-local message for the last failing call.
+ */
+#ifndef AMBER_MPN_H
+#define AMBER_MPN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AMBER_MPN_ABI_VERSION 1
+#define AMBER_MPN_MAX_MLP_LAYERS 4
+#define AMBER_MPN_TILE 32 /* sorted edges per wave tile; partial-sum buffers are indexed by edge position / TILE */
+
+enum {
+  AMBER_OK = 0,
+  AMBER_ERR_INVALID_ARGUMENT = -1,
+  AMBER_ERR_UNSUPPORTED = -2,
+  AMBER_ERR_WORKSPACE_TOO_SMALL = -3,
+  AMBER_ERR_HIP = -4
+};
+
+/* activation functions: LatentMLP (src/mpn/common/latent_mlp.py:76-83) uses the first three,
+ * the decoder MLP (src/algorithm/architecture/mlp.py:68-83) all of them; torch default arguments. */
+enum {
+  AMBER_ACT_RELU = 0,
+  AMBER_ACT_LEAKYRELU = 1, /* negative slope 0.01 */
+  AMBER_ACT_TANH = 2,
+  AMBER_ACT_ELU = 3,
+  AMBER_ACT_SILU = 4,
+  AMBER_ACT_MISH = 5,
+  AMBER_ACT_GELU = 6 /* exact erf form */
+};
+
+/* residual_connections / layer_norm placement (src/mpn/message_passing_block.py:34-38,62-74) */
+enum { AMBER_MODE_NONE = 0, AMBER_MODE_INNER = 1, AMBER_MODE_OUTER = 2 };
+
+/* decoder latent_normalization (src/algorithm/architecture/mlp.py:86-89), eval mode */
+enum { AMBER_NORM_NONE = 0, AMBER_NORM_LAYER = 1, AMBER_NORM_AFFINE = 2 /* BatchNorm1d folded to scale, shift */ };
+
+/* precision of the MLP contractions */
+enum {
+  AMBER_PREC_FP32 = 0 /* exact fp32 MFMA (v_mfma_f32_32x32x2_f32), tolerance 1e-5 */
+};
+
+/* Static description of the network: the hyper-parameters the reference reads from
+ * config/algorithm/architecture/mpn.yaml ("Config / flags"). */
+typedef struct AmberMpnDesc {
+  int32_t latent;             /* latent_dimension: 32, 64 or 128 */
+  int32_t num_steps;          /* stack.num_steps: blocks with their own weights */
+  int32_t num_step_repeats;   /* stack.num_step_repeats: each block applied this often */
+  int32_t mlp_layers;         /* stack.mlp.num_layers, 1..AMBER_MPN_MAX_MLP_LAYERS */
+  int32_t activation;         /* stack.mlp.activation_function */
+  int32_t residual;           /* AMBER_MODE_* */
+  int32_t layer_norm;         /* AMBER_MODE_* */
+  int32_t in_node_features;   /* F_n >= 0 (0 = learned constant embedding, empty_linear_layer.py:44-45) */
+  int32_t in_edge_features;   /* F_e >= 0 */
+  int32_t embed_layers;       /* 0 = nn.Linear embedding; k > 0 = LatentMLP embedding with k layers (embedding.py:32-38) */
+  int32_t embed_activation;   /* activation of the embedding MLP */
+  int32_t has_head;           /* 1 = SupervisedMPN decoder MLP + readout Linear(L,1) follow (supervised_mpn.py:51-54) */
+  int32_t decoder_layers;     /* decoder.num_layers, 0..AMBER_MPN_MAX_MLP_LAYERS */
+  int32_t decoder_activation; /* decoder.activation_function */
+  int32_t decoder_norm;       /* AMBER_NORM_* applied after each decoder activation */
+  int32_t precision;          /* AMBER_PREC_* */
+  float ln_eps;               /* LayerNorm eps (torch default 1e-5) */
+} AmberMpnDesc;
+
+/* ---------------------------------------------------------------------------------------------------
+ * Parameters.  The caller concatenates the module's parameters, each in its nn.Linear / nn.LayerNorm
+ * layout ([out, in] row-major weights), into ONE fp32 device buffer in this order:
+ *
+ *   node embedding, then edge embedding; each is
+ *       F == 0            : bias[L]
+ *       embed_layers == 0 : W[L,F], b[L]
+ *       embed_layers  > 0 : W0[L,F], b0[L], then (embed_layers-1) x { W[L,L], b[L] }
+ *   for every step s < num_steps:
+ *       edge MLP : W0[L,3L], b0[L], then (mlp_layers-1) x { W[L,L], b[L] }      (columns: x[src] | x[dst] | e)
+ *       node MLP : W0[L,2L], b0[L], then (mlp_layers-1) x { W[L,L], b[L] }      (columns: x | mean of incoming e)
+ *       if layer_norm != NONE: edge LN gamma[L], beta[L], node LN gamma[L], beta[L]
+ *   if has_head:
+ *       decoder_layers x { W[L,L], b[L], and if decoder_norm != NONE: p[L], q[L] }
+ *           (LAYER: p = gamma, q = beta;  AFFINE: p = scale, q = shift of the folded eval BatchNorm)
+ *       readout w[L], b[1]
+ *
+ * amber_mpn_pack_weights re-tiles the L x L matrices into the MFMA operand order the kernels read
+ * (`packed`, amber_mpn_packed_floats(desc) floats).  Both buffers are passed to every compute call.
+ * ------------------------------------------------------------------------------------------------- */
+int64_t amber_mpn_param_floats(const AmberMpnDesc* desc);
+int64_t amber_mpn_packed_floats(const AmberMpnDesc* desc);
+int amber_mpn_pack_weights(const AmberMpnDesc* desc, const float* params, float* packed, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * CSR construction: destination-sorted, stable (inside a destination's row the edges keep their
+ * edge_index order, i.e. the order torch_scatter's scatter_add visits them).  Built once per mesh.
+ * Replaces the implicit per-call index handling of scatter_mean(edge_attr, dest_indices, ...)
+ * (src/mpn/message_passing_modules.py:46-48,67-68).  Bit-exact vs torch.sort(dst, stable=True).
+ *   edge_index : int64 [2, E], row 0 = source, row 1 = destination
+ *   rowptr[N+1], src_sorted[E], dst_sorted[E], perm[E] (perm[p] = original edge id at sorted position p)
+ *   status     : int32[1], set to 0, or 1 if an index is outside [0, N) (offending edges are clamped)
+ * ------------------------------------------------------------------------------------------------- */
+size_t amber_mpn_csr_workspace_bytes(int64_t num_nodes, int64_t num_edges);
+int amber_mpn_csr_build(const int64_t* edge_index, int64_t num_edges, int64_t num_nodes, int32_t* rowptr,
+                        int32_t* src_sorted, int32_t* dst_sorted, int32_t* perm, int32_t* status, void* workspace,
+                        size_t workspace_bytes, void* stream);
+
+/* Deterministic segmented mean over CSR rows, no float atomics: out[n] = sum(values[rowptr[n]:rowptr[n+1]]) /
+ * max(deg, 1), summed in row order.  Replaces torch_scatter.scatter_mean at
+ * src/mpn/message_passing_modules.py:68 (values already destination-sorted).  L % 4 == 0, L <= 1024. */
+int amber_mpn_segment_mean(const float* values_sorted, const int32_t* rowptr, int64_t num_nodes, int64_t num_edges,
+                           int32_t latent, float* out, void* stream);
+
+/* Row gather / scatter between edge_index order and CSR order: out[p] = in[perm[p]] (gather = 1) or
+ * out[perm[p]] = in[p] (gather = 0); rows of `width` floats (width % 4 == 0). */
+int amber_mpn_permute_rows(const float* in, const int32_t* perm, int64_t rows, int32_t width, int32_t gather,
+                           float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Stage entry points (each mirrors one reference module; used for per-stage parity tests and by hosts
+ * that drive the stack themselves).  `workspace` must hold amber_mpn_workspace_bytes(desc, N, E) bytes.
+ * ------------------------------------------------------------------------------------------------- */
+size_t amber_mpn_workspace_bytes(const AmberMpnDesc* desc, int64_t num_nodes, int64_t num_edges);
+
+/* MessagePassingInputEmbedding.forward (src/mpn/input_embedding.py:33-42; Embedding, EmptyLinear):
+ * x_latent[N,L] = embed(x_raw[N,F_n]);  e_latent_sorted[E,L] = embed(edge_attr_raw[perm][E,F_e]). */
+int amber_mpn_embed(const AmberMpnDesc* desc, const float* params, const float* packed, int64_t num_nodes,
+                    int64_t num_edges, const float* x_raw, const float* edge_attr_raw, const int32_t* perm,
+                    float* x_latent, float* e_latent_sorted, void* workspace, size_t workspace_bytes, void* stream);
+
+/* MessagePassingBlock.forward for block `step` (src/mpn/message_passing_block.py:107-128; edge module
+ * message_passing_modules.py:38-52, node module :61-72), in place on latent features:
+ * x_latent[N,L] and e_latent_sorted[E,L] (CSR order). */
+int amber_mpn_block(const AmberMpnDesc* desc, const float* params, const float* packed, int32_t step,
+                    int64_t num_nodes, int64_t num_edges, const int32_t* rowptr, const int32_t* src_sorted,
+                    const int32_t* dst_sorted, float* x_latent, float* e_latent_sorted, void* workspace,
+                    size_t workspace_bytes, void* stream);
+
+/* SupervisedMPN head (src/algorithm/architecture/supervised_mpn.py:51-54; MLP mlp.py:60-95):
+ * out_sizing[out_index[n]] = readout(decoder(x_latent[n])) for every n with out_index[n] >= 0
+ * (out_index == NULL: identity).  out_index encodes x[mask_output]: the rank of n among kept nodes. */
+int amber_mpn_head(const AmberMpnDesc* desc, const float* params, const float* packed, int64_t num_nodes,
+                   const float* x_latent, const int32_t* out_index, float* out_sizing, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * The whole path in one call: MessagePassingBase.forward (src/mpn/message_passing_base.py:127-146, eval mode:
+ * edge dropout is the identity, src/mpn/common/edge_dropout.py:24) followed, if desc->has_head, by the
+ * SupervisedMPN head.  Inputs are never written (the create_graph_copy guarantee, mpn_util.py:82-83).
+ *   x[N,F_n], edge_attr[E,F_e] (edge_index order), CSR from amber_mpn_csr_build
+ *   out_node  [N,L]  or NULL : final node latents  ({"node": x} of unpack_features, mpn_util.py:22-46)
+ *   out_edge  [E,L]  or NULL : final edge latents in edge_index order
+ *   out_sizing[N_m]  or NULL : head output (requires has_head); out_index as in amber_mpn_head
+ * ------------------------------------------------------------------------------------------------- */
+int amber_mpn_forward(const AmberMpnDesc* desc, const float* params, const float* packed, int64_t num_nodes,
+                      int64_t num_edges, const float* x, const float* edge_attr, const int32_t* rowptr,
+                      const int32_t* src_sorted, const int32_t* dst_sorted, const int32_t* perm,
+                      const int32_t* out_index, float* out_node, float* out_edge, float* out_sizing,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* Timing hook for benchmarks: like amber_mpn_forward, and additionally records HIP events around every
+ * kernel launch ON `stream` and, after synchronising it, writes per-kernel-class device milliseconds to
+ * the HOST array kernel_ms[AMBER_MPN_NUM_KERNEL_CLASSES] (accumulated over the call).  Synchronises. */
+#define AMBER_MPN_NUM_KERNEL_CLASSES 4
+enum { AMBER_KC_EMBED = 0, AMBER_KC_EDGE = 1, AMBER_KC_NODE = 2, AMBER_KC_OTHER = 3 };
+int amber_mpn_forward_timed(const AmberMpnDesc* desc, const float* params, const float* packed, int64_t num_nodes,
+                            int64_t num_edges, const float* x, const float* edge_attr, const int32_t* rowptr,
+                            const int32_t* src_sorted, const int32_t* dst_sorted, const int32_t* perm,
+                            const int32_t* out_index, float* out_node, float* out_edge, float* out_sizing,
+                            void* workspace, size_t workspace_bytes, void* stream, float* kernel_ms,
+                            int32_t* kernel_launches);
+
+int amber_mpn_abi_version(void);
+const char* amber_mpn_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AMBER_MPN_H */

@@ -1,0 +1,327 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the reference-generated golden
+vectors.  Needs an MI355X: run with `-m gpu`.
+
+Bars (BASELINE.json north_star): CSR / index work bit-exact; fp32 outputs within 1e-5 relative error,
+measured as max|a - b| / max|b| over the tensor (error relative to the output's scale)."""
+import numpy as np
+import pytest
+import torch
+
+from amber_amd import csr as csr_mod
+from amber_amd import engine, synthetic as syn
+from amber_amd.architecture.supervised_mpn import SupervisedMPN
+from amber_amd.config import AttrDict
+from amber_amd.mpn.get_message_passing_base import get_mpn
+from conftest import golden_cases, load_golden, rel_err
+from oracle import mpn_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+FP32_TOL = 1e-5
+
+
+def _model_from_golden(cfg, params, data, device):
+    example = syn.GraphBatch(x=data["x"], edge_attr=data["edge_attr"])
+    model = SupervisedMPN(AttrDict(cfg), example)
+    missing = model.load_state_dict(params, strict=True)  # reference checkpoint names must load as they are
+    assert not missing.missing_keys and not missing.unexpected_keys
+    return model.to(device).eval()
+
+
+def _batch(data, device, with_mask=True):
+    kw = dict(x=data["x"].to(device), edge_attr=data["edge_attr"].to(device), edge_index=data["edge_index"].to(device),
+              batch=data["batch"].to(device))
+    if with_mask:
+        kw["mask_output"] = data["mask_output"].to(device)
+    return syn.GraphBatch(**kw)
+
+
+# ------------------------------------------------------------------------------------------------------
+# CSR: bit-exact
+# ------------------------------------------------------------------------------------------------------
+def _check_csr(ei_np, n, device):
+    csr = csr_mod.build_csr(torch.from_numpy(ei_np).to(device), n)
+    rowptr, perm, src_s, dst_s = orc.csr_oracle(ei_np, n)
+    assert np.array_equal(csr.rowptr.cpu().numpy(), rowptr)
+    assert np.array_equal(csr.perm.cpu().numpy(), perm)
+    assert np.array_equal(csr.src_sorted.cpu().numpy(), src_s)
+    assert np.array_equal(csr.dst_sorted.cpu().numpy(), dst_s)
+    return csr
+
+
+@pytest.mark.parametrize("n,e,seed", [(1, 1, 0), (7, 0, 1), (50, 400, 2), (5000, 40000, 3), (100000, 700000, 4), (33, 5000, 5)])
+def test_csr_random_bit_exact(gpu_device, n, e, seed):
+    rng = np.random.default_rng(seed)
+    _check_csr(syn.random_graph(n, e, rng, isolated=n // 10), n, gpu_device)
+
+
+def test_csr_mesh_and_hub_rows_bit_exact(gpu_device):
+    rng = np.random.default_rng(7)
+    el, n, _ = syn.hierarchical_graph(40, 30, 2, 2, rng)  # 4 hub rows of ~300 edges (> the short-row path)
+    csr = _check_csr(el, n, gpu_device)
+    assert int(np.diff(csr.rowptr.cpu().numpy()).max()) > 64
+    g = syn.grid_batch(num_graphs=3, nx=50, ny=40)
+    _check_csr(g.edge_index.numpy(), int(g.x.shape[0]), gpu_device)
+    # equals torch's stable sort as well
+    t = torch.sort(g.edge_index[1], stable=True)
+    csr = csr_mod.build_csr(g.edge_index.to(gpu_device), int(g.x.shape[0]))
+    assert torch.equal(csr.perm.cpu().long(), t.indices)
+
+
+def test_csr_rejects_out_of_range_indices(gpu_device):
+    ei = torch.tensor([[0, 1, 2], [1, 2, 9]], device=gpu_device)
+    with pytest.raises(IndexError):
+        csr_mod.build_csr(ei, 3)
+    with pytest.raises(ValueError):
+        csr_mod.build_csr(torch.zeros(3, 4, dtype=torch.long, device=gpu_device), 3)
+
+
+def test_segment_mean_matches_scatter_mean(gpu_device):
+    rng = np.random.default_rng(11)
+    n, e, L = 3000, 20000, 128
+    ei = syn.random_graph(n, e, rng, isolated=100)
+    csr = csr_mod.build_csr(torch.from_numpy(ei).to(gpu_device), n)
+    vals = torch.randn(e, L)
+    got = csr_mod.segment_mean(vals.to(gpu_device)[csr.perm.long()], csr.rowptr).cpu()
+    want = orc.scatter_mean(vals, torch.from_numpy(ei[1]), n)
+    # same summation order (stable sort) and the same division: bit-exact
+    assert torch.equal(got, want)
+    assert torch.equal(got[n - 100:], torch.zeros(100, L))  # zero in-degree rows
+
+
+def test_permute_rows_roundtrip(gpu_device):
+    perm = torch.randperm(1000, device=gpu_device).int()
+    rows = torch.randn(1000, 64, device=gpu_device)
+    g = csr_mod.permute_rows(rows, perm, gather=True)
+    assert torch.equal(g, rows[perm.long()])
+    assert torch.equal(csr_mod.permute_rows(g, perm, gather=False), rows)
+
+
+# ------------------------------------------------------------------------------------------------------
+# golden vectors (outputs of the reference's own classes)
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", golden_cases())
+def test_forward_matches_reference_golden(gpu_device, name):
+    cfg, params, d = load_golden(name)
+    model = _model_from_golden(cfg, params, d, gpu_device)
+    batch = _batch(d, gpu_device)
+    x_before, e_before = batch.x.clone(), batch.edge_attr.clone()
+    with torch.no_grad():
+        out = model(batch)
+        nodes, edges, bvec = model.mpn(batch)
+    assert out.shape == d["out_sizing"].shape
+    assert rel_err(out.cpu(), d["out_sizing"]) <= FP32_TOL
+    assert rel_err(nodes["node"].cpu(), d["out_node"]) <= FP32_TOL
+    assert rel_err(edges["edges"]["edge_attr"].cpu(), d["out_edge"]) <= FP32_TOL
+    assert torch.equal(edges["edges"]["edge_index"].cpu(), d["edge_index"])
+    assert torch.equal(bvec["node"].cpu(), d["batch"])
+    # create_graph_copy=True: the caller's batch is untouched
+    assert torch.equal(batch.x, x_before) and torch.equal(batch.edge_attr, e_before)
+
+
+def test_forward_without_mask_and_without_batch_vector(gpu_device):
+    cfg, params, d = load_golden("hier_L64_s3")
+    model = _model_from_golden(cfg, params, d, gpu_device)
+    batch = _batch(d, gpu_device, with_mask=False)
+    del batch.batch
+    with torch.no_grad():
+        out = model(batch)
+        _, _, bvec = model.mpn(batch)
+    want = orc.supervised_mpn_forward(params, cfg, d["x"], d["edge_attr"], d["edge_index"], None)
+    assert out.shape == (d["x"].shape[0], 1)
+    assert rel_err(out.cpu(), want) <= FP32_TOL
+    assert torch.equal(bvec["node"], torch.zeros(d["x"].shape[0]).long())  # unpack_features default
+
+
+# ------------------------------------------------------------------------------------------------------
+# per-stage parity against the oracle (embedding, every block, head)
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["debug_L64_s2", "synth_L128_s2", "outer_relu_L32", "mix_oi_L32", "repeat_L32_l3"])
+def test_stage_entry_points_match_oracle(gpu_device, name):
+    cfg, params, d = load_golden(name)
+    model = _model_from_golden(cfg, params, d, gpu_device)
+    mpn = model.mpn
+    csr = csr_mod.build_csr(d["edge_index"].to(gpu_device), int(d["x"].shape[0]))
+    desc = engine.make_desc(**mpn.desc_kwargs())
+    flat, packed = engine.PackedParams().get(desc, mpn.param_list())
+    _, _, steps = orc.mpn_forward(params, cfg, d["x"], d["edge_attr"], d["edge_index"], prefix="mpn.", collect_steps=True)
+    x, e = engine.embed(desc, flat, packed, d["x"].to(gpu_device), d["edge_attr"].to(gpu_device), csr)
+    perm = csr.perm.long().cpu()
+    assert rel_err(x.cpu(), steps[0][0]) <= FP32_TOL
+    assert rel_err(e.cpu(), steps[0][1][perm]) <= FP32_TOL
+    it = 0
+    for s in range(cfg["stack"]["num_steps"]):
+        for _ in range(cfg["stack"].get("num_step_repeats", 1)):
+            engine.block(desc, flat, packed, s, x, e, csr)
+            it += 1
+            assert rel_err(x.cpu(), steps[it][0]) <= FP32_TOL, f"node features after block application {it}"
+            assert rel_err(e.cpu(), steps[it][1][perm]) <= FP32_TOL, f"edge features after block application {it}"
+    # head on the oracle's latents
+    hdesc = engine.make_desc(has_head=True, decoder_layers=cfg["decoder"]["num_layers"],
+                             decoder_activation=cfg["decoder"]["activation_function"],
+                             decoder_norm=cfg["decoder"]["regularization"]["latent_normalization"], **mpn.desc_kwargs())
+    pieces, _ = model.decoder_mlp.param_list(single_row=False)
+    hflat, hpacked = engine.PackedParams().get(hdesc, mpn.param_list() + pieces + [model.readout.weight, model.readout.bias])
+    oi, n_out = engine.out_index_from_mask(d["mask_output"].to(gpu_device))
+    got = engine.head(hdesc, hflat, hpacked, steps[-1][0].to(gpu_device).contiguous(), oi, n_out)
+    dec = orc.decoder_mlp(params, "decoder_mlp", steps[-1][0][d["mask_output"]], cfg["decoder"], cfg["latent_dimension"])
+    want = torch.nn.functional.linear(dec, params["readout.weight"], params["readout.bias"])
+    assert rel_err(got.cpu(), want) <= FP32_TOL
+
+
+def test_block_and_stack_modules_work_in_place_on_latent_graphs(gpu_device):
+    cfg, params, d = load_golden("debug_L64_s2")
+    model = _model_from_golden(cfg, params, d, gpu_device)
+    _, _, steps = orc.mpn_forward(params, cfg, d["x"], d["edge_attr"], d["edge_index"], prefix="mpn.", collect_steps=True)
+    g = syn.GraphBatch(x=steps[0][0].to(gpu_device), edge_attr=steps[0][1].to(gpu_device), edge_index=d["edge_index"].to(gpu_device))
+    model.mpn.message_passing_stack(g)
+    assert rel_err(g.x.cpu(), steps[-1][0]) <= FP32_TOL
+    assert rel_err(g.edge_attr.cpu(), steps[-1][1]) <= FP32_TOL
+    raw = _batch(d, gpu_device)
+    model.mpn.input_embeddings(raw)
+    assert rel_err(raw.x.cpu(), steps[0][0]) <= FP32_TOL and rel_err(raw.edge_attr.cpu(), steps[0][1]) <= FP32_TOL
+
+
+# ------------------------------------------------------------------------------------------------------
+# interface behaviour
+# ------------------------------------------------------------------------------------------------------
+def _mpn_cfg(latent=32, steps=2, **kw):
+    cfg = {"create_graph_copy": True, "assert_graph_shapes": True, "edge_dropout": 0.1, "embedding": None,
+           "stack": {"layer_norm": "inner", "num_steps": steps, "residual_connections": "inner",
+                     "mlp": {"activation_function": "leakyrelu", "num_layers": 2}}}
+    cfg.update(kw)
+    return cfg
+
+
+def test_create_graph_copy_false_mutates_and_graph_output_returns_none(gpu_device):
+    torch.manual_seed(0)
+    g = syn.grid_batch(num_graphs=2, nx=9, ny=7).to(gpu_device)
+    mpn = get_mpn(in_node_features=4, in_edge_features=2, latent_dimension=32, base_config=_mpn_cfg(create_graph_copy=False),
+                  device=gpu_device).eval()
+    sd = {k: v.cpu() for k, v in mpn.state_dict().items()}
+    cfg = dict(_mpn_cfg(), latent_dimension=32, in_node_features=4, in_edge_features=2)
+    wx, we = orc.mpn_forward(sd, cfg, g.x.cpu(), g.edge_attr.cpu(), g.edge_index.cpu())
+    with torch.no_grad():
+        nodes, edges, _ = mpn(g)
+    assert g.x.shape == (g.x.shape[0], 32) and g.x is nodes["node"]  # mutated in place, like the reference
+    assert rel_err(g.x.cpu(), wx) <= FP32_TOL and rel_err(g.edge_attr.cpu(), we) <= FP32_TOL
+    mpn2 = get_mpn(in_node_features=4, in_edge_features=2, latent_dimension=32, base_config=_mpn_cfg(), device=gpu_device).eval()
+    mpn2._output_type = "graph"
+    g2 = syn.grid_batch(num_graphs=1, nx=5, ny=5).to(gpu_device)
+    assert mpn2(g2) is None and g2.x.shape[1] == 4
+
+
+def test_errors_mirror_the_reference(gpu_device):
+    mpn = get_mpn(in_node_features=4, in_edge_features=2, latent_dimension=32, base_config=_mpn_cfg(), device=gpu_device).eval()
+    g = syn.grid_batch(num_graphs=1, nx=5, ny=5, in_node_features=3).to(gpu_device)
+    with pytest.raises(AssertionError, match="Feature dimensions of nodes do not match"):
+        mpn(g)
+    cpu_graph = syn.grid_batch(num_graphs=1, nx=5, ny=5)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        mpn(cpu_graph)
+    mpn.train()
+    with pytest.raises(NotImplementedError):
+        mpn(syn.grid_batch(num_graphs=1, nx=5, ny=5).to(gpu_device))
+    with pytest.raises(ValueError, match="Unknown activation function"):
+        get_mpn(in_node_features=4, in_edge_features=2, latent_dimension=32, device=gpu_device,
+                base_config=_mpn_cfg(stack={"layer_norm": None, "num_steps": 1, "residual_connections": None,
+                                            "mlp": {"activation_function": "swiglu", "num_layers": 2}}))
+
+
+def test_empty_and_ragged_inputs(gpu_device):
+    mpn = get_mpn(in_node_features=4, in_edge_features=2, latent_dimension=64, base_config=_mpn_cfg(), device=gpu_device).eval()
+    sd = {k: v.cpu() for k, v in mpn.state_dict().items()}
+    cfg = dict(_mpn_cfg(), latent_dimension=64, in_node_features=4, in_edge_features=2)
+    # nodes without any edge (E = 0): every aggregate is zero
+    g = syn.GraphBatch(x=torch.randn(37, 4), edge_attr=torch.zeros(0, 2), edge_index=torch.zeros(2, 0, dtype=torch.long)).to(gpu_device)
+    with torch.no_grad():
+        nodes, edges, _ = mpn(g)
+    wx, we = orc.mpn_forward(sd, cfg, g.x.cpu(), g.edge_attr.cpu(), g.edge_index.cpu())
+    assert edges["edges"]["edge_attr"].shape == (0, 64) and rel_err(nodes["node"].cpu(), wx) <= FP32_TOL
+    # ragged sizes around the 32-row tile: 1, 31, 32, 33 nodes / edges; one row spanning several tiles
+    rng = np.random.default_rng(5)
+    for n, e in [(1, 1), (31, 33), (32, 32), (33, 31), (3, 200)]:
+        ei = syn.random_graph(n, e, rng)
+        g = syn.GraphBatch(x=torch.randn(n, 4), edge_attr=torch.randn(e, 2), edge_index=torch.from_numpy(ei)).to(gpu_device)
+        with torch.no_grad():
+            nodes, edges, _ = mpn(g)
+        wx, we = orc.mpn_forward(sd, cfg, g.x.cpu(), g.edge_attr.cpu(), g.edge_index.cpu())
+        assert rel_err(nodes["node"].cpu(), wx) <= FP32_TOL, (n, e)
+        assert rel_err(edges["edges"]["edge_attr"].cpu(), we) <= FP32_TOL, (n, e)
+
+
+# ------------------------------------------------------------------------------------------------------
+# mid-size oracle parity at the BASELINE configurations' shapes
+# ------------------------------------------------------------------------------------------------------
+def _supervised(latent, steps, fn, fe, device, seed=0):
+    torch.manual_seed(seed)
+    cfg = {"latent_dimension": latent, "create_graph_copy": True, "assert_graph_shapes": False, "edge_dropout": 0.1,
+           "embedding": None,
+           "stack": {"layer_norm": "inner", "num_steps": steps, "residual_connections": "inner",
+                     "mlp": {"activation_function": "leakyrelu", "num_layers": 2}},
+           "decoder": {"activation_function": "leakyrelu", "num_layers": 2,
+                       "regularization": {"dropout": 0, "spectral_norm": False, "latent_normalization": None}}}
+    example = syn.GraphBatch(x=torch.zeros(1, fn), edge_attr=torch.zeros(1, fe))
+    model = SupervisedMPN(AttrDict(cfg), example)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if "layer_norm" in name:
+                p.add_(0.1 * torch.randn(p.shape))
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    return model.to(device).eval(), sd, dict(cfg, in_node_features=fn, in_edge_features=fe)
+
+
+@pytest.mark.parametrize("latent,steps,graphs,nx,ny", [(64, 20, 3, 60, 50), (128, 10, 2, 120, 120)])
+def test_paper_and_synthetic_shapes_match_oracle(gpu_device, latent, steps, graphs, nx, ny):
+    """Config 'paper runs' (L=64, 20 steps) and config 5's network (L=128, 10 steps) on a CPU-sized batch."""
+    model, sd, cfg = _supervised(latent, steps, 4, 2, gpu_device)
+    g = syn.grid_batch(num_graphs=graphs, nx=nx, ny=ny)
+    want = orc.supervised_mpn_forward(sd, cfg, g.x, g.edge_attr, g.edge_index, g.mask_output)
+    with torch.no_grad():
+        got = model(g.to(gpu_device))
+    assert rel_err(got.cpu(), want) <= FP32_TOL
+
+
+def test_3d_like_and_hierarchical_graphs_match_oracle(gpu_device):
+    model, sd, cfg = _supervised(64, 5, 4, 2, gpu_device, seed=3)
+    g = syn.brick_batch(2, 14, 12, 10)  # in-degree ~15
+    want = orc.supervised_mpn_forward(sd, cfg, g.x, g.edge_attr, g.edge_index, g.mask_output)
+    with torch.no_grad():
+        got = model(g.to(gpu_device))
+    assert rel_err(got.cpu(), want) <= FP32_TOL
+    rng = np.random.default_rng(9)
+    parts = [syn.hierarchical_graph(60, 50, 3, 3, rng), syn.hierarchical_graph(40, 45, 2, 3, rng)]  # hub rows of ~300-500 edges
+    g = syn.make_batch([p[0] for p in parts], [p[1] for p in parts], 4, 2, mask_outputs=[p[2] for p in parts])
+    want = orc.supervised_mpn_forward(sd, cfg, g.x, g.edge_attr, g.edge_index, g.mask_output)
+    with torch.no_grad():
+        got = model(g.to(gpu_device))
+    assert got.shape == want.shape and rel_err(got.cpu(), want) <= FP32_TOL
+
+
+# ------------------------------------------------------------------------------------------------------
+# full BASELINE size: size-independent properties
+# ------------------------------------------------------------------------------------------------------
+def test_full_size_batch_properties(gpu_device):
+    """BASELINE config 5 (100 x 120x120 grids, N = 1.44M, E = 9.98M, L = 128, 10 steps), too big for the oracle:
+    (1) run-to-run bit-equality (deterministic reduction, no float atomics);
+    (2) disjoint-union invariance: graphs never exchange messages, so graph g's outputs inside the batch equal
+        the outputs of graph g run alone -- and that single graph IS oracle-sized, which anchors the full run."""
+    model, sd, cfg = _supervised(128, 10, 4, 2, gpu_device)
+    g = syn.grid_batch(num_graphs=100, nx=120, ny=120)
+    assert g.x.shape[0] == 1_440_000 and g.edge_index.shape[1] == 9_984_200
+    gd = g.to(gpu_device)
+    with torch.no_grad():
+        out1 = model(gd)
+        out2 = model(gd)
+    assert torch.equal(out1, out2)
+    assert torch.isfinite(out1).all()
+    for gi in (0, 57, 99):
+        n0, n1 = int(g.ptr[gi]), int(g.ptr[gi + 1])
+        e0, e1 = int(g.edge_ptr[gi]), int(g.edge_ptr[gi + 1])
+        x, ea, ei = g.x[n0:n1], g.edge_attr[e0:e1], g.edge_index[:, e0:e1] - n0
+        want = orc.supervised_mpn_forward(sd, cfg, x, ea, ei, None)
+        assert rel_err(out1[n0:n1].cpu(), want) <= FP32_TOL
+        alone = syn.GraphBatch(x=x, edge_attr=ea, edge_index=ei).to(gpu_device)
+        with torch.no_grad():
+            got_alone = model(alone)
+        assert rel_err(got_alone, out1[n0:n1]) <= 2e-6
