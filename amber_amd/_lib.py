@@ -77,6 +77,11 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch must be loaded FIRST: it bundles its own libamdhip64.so (SONAME libamdhip64.so.7), which then also
+    # satisfies this library's dependency, so both share ONE HIP runtime (device pointers, streams).  Loaded
+    # the other way round, the process ends up with two runtimes and every call here fails with "no device".
+    import torch  # noqa: F401
+
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"amber_amd: HIP extension not built ({LIB_PATH} missing). Run `make -C amber_amd/csrc` "

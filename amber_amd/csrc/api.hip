@@ -54,6 +54,7 @@ struct Layout {
 };
 
 int validate(const AmberMpnDesc* d) {
+  (void)hipGetLastError();  // drop a stale error left by an earlier, unrelated runtime call of this thread
   if (!d) return fail(AMBER_ERR_INVALID_ARGUMENT, "desc is NULL");
   if (d->latent != 32 && d->latent != 64 && d->latent != 128)
     return fail(AMBER_ERR_UNSUPPORTED, "latent_dimension %d not supported (32, 64, 128)", d->latent);
@@ -493,6 +494,7 @@ int amber_mpn_csr_build(const int64_t* edge_index, int64_t num_edges, int64_t nu
   if (workspace_bytes < amber_mpn_csr_workspace_bytes(num_nodes, num_edges))
     return fail(AMBER_ERR_WORKSPACE_TOO_SMALL, "csr workspace %zu < %zu bytes", workspace_bytes,
                 amber_mpn_csr_workspace_bytes(num_nodes, num_edges));
+  (void)hipGetLastError();
   // carve from a 256-byte aligned base
   uintptr_t base = (reinterpret_cast<uintptr_t>(workspace) + 255) & ~static_cast<uintptr_t>(255);
   HIP_TRY(csr_build(edge_index, num_edges, num_nodes, rowptr, src_sorted, dst_sorted, perm, status, reinterpret_cast<void*>(base),
@@ -507,6 +509,7 @@ int amber_mpn_segment_mean(const float* values_sorted, const int32_t* rowptr, in
   if (latent <= 0 || latent % 4 != 0 || latent > 1024) return fail(AMBER_ERR_UNSUPPORTED, "latent %d: need a multiple of 4, <= 1024", latent);
   if (num_nodes > 0 && (!rowptr || !out)) return fail(AMBER_ERR_INVALID_ARGUMENT, "rowptr / out is NULL");
   if (num_edges > 0 && !values_sorted) return fail(AMBER_ERR_INVALID_ARGUMENT, "values is NULL");
+  (void)hipGetLastError();
   HIP_TRY(launch_segment_mean(values_sorted, rowptr, num_nodes, latent, out, static_cast<hipStream_t>(stream)), "segment_mean");
   return AMBER_OK;
 }
@@ -515,6 +518,7 @@ int amber_mpn_permute_rows(const float* in, const int32_t* perm, int64_t rows, i
                            void* stream) {
   if (rows < 0 || width <= 0 || width % 4 != 0) return fail(AMBER_ERR_INVALID_ARGUMENT, "bad rows / width");
   if (rows > 0 && (!in || !perm || !out)) return fail(AMBER_ERR_INVALID_ARGUMENT, "NULL pointer");
+  (void)hipGetLastError();
   HIP_TRY(launch_permute_rows(in, perm, rows, width, gather, out, static_cast<hipStream_t>(stream)), "permute_rows");
   return AMBER_OK;
 }

@@ -63,8 +63,8 @@ struct NodeArgs {
   DenseLayer layers[kMaxLayers];  // layers[1..nl-1]
   int32_t nl;
   int32_t act;
-  int32_t residual;       // != NONE: add x_in
-  int32_t layer_norm;     // != NONE: LayerNorm(gamma, beta)
+  int32_t residual;       // AMBER_MODE_*: add x_in before (inner) or after (outer) the inner LayerNorm
+  int32_t layer_norm;     // AMBER_MODE_*
   const float* gamma;
   const float* beta;
   float eps;

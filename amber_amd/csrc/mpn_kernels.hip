@@ -412,9 +412,11 @@ __global__ __launch_bounds__(kBlock) void node_kernel(const NodeArgs a, const in
       tile_act<L>(nxt, a.act, stage, lane);
       acc = nxt;
     }
-    // inner and outer placement coincide for nodes: nothing reads x between them (block.py:124-128)
-    if (a.residual != AMBER_MODE_NONE) tile_add<L>(acc, v);
-    if (a.layer_norm != AMBER_MODE_NONE) tile_layernorm<L>(acc, a.gamma, a.beta, a.eps, h);
+    // order of message_passing_block.py:124-128: inner residual, inner LN, outer residual, outer LN
+    if (a.residual == AMBER_MODE_INNER) tile_add<L>(acc, v);
+    if (a.layer_norm == AMBER_MODE_INNER) tile_layernorm<L>(acc, a.gamma, a.beta, a.eps, h);
+    if (a.residual == AMBER_MODE_OUTER) tile_add<L>(acc, v);
+    if (a.layer_norm == AMBER_MODE_OUTER) tile_layernorm<L>(acc, a.gamma, a.beta, a.eps, h);
     v = acc;
   }
   if (a.x_out) {

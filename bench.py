@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""MPN forward throughput on MI355X (BASELINE.json metric: MPN forward edges/s on the 10M-edge mesh batch).
+
+One "step" = one SupervisedMPN forward (K0-K10: embeddings, 10 message passing steps, decoder + readout) over
+one synthetic disjoint batch of 100 triangulated 120x120 grids (N = 1,440,000, E = 9,984,200, L = 128), inputs
+already resident in HBM, CSR built once per mesh before the timed region (reported separately).
+
+  python bench.py --gpus 1 --steps 10 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Graph-wise data parallelism, no data-path collective: by default every rank processes its own 10M-edge batch
+("weak"); --scaling strong shards the ONE 100-graph batch across the ranks at graph boundaries instead.
+Rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+from amber_amd import csr as csr_mod  # noqa: E402
+from amber_amd import engine, sharding, synthetic as syn  # noqa: E402
+from amber_amd.architecture.supervised_mpn import SupervisedMPN  # noqa: E402
+from amber_amd.config import default_architecture  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+FP32_MFMA_PEAK_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32 dense peak (same guide)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--graphs", type=int, default=100, help="graphs per batch (100 = BASELINE config 5)")
+    ap.add_argument("--nx", type=int, default=120)
+    ap.add_argument("--ny", type=int, default=120)
+    ap.add_argument("--latent", type=int, default=128)
+    ap.add_argument("--mp-steps", type=int, default=10)
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-graphs", type=int, default=10, help="graphs in the CPU-baseline sample (10 = 1M edges)")
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg, state_dict, args):
+    """The reference CPU path (oracle = torch-CPU restatement of the reference forward) on the host cores,
+    on a bounded sample of the same workload: `cpu_graphs` of the 120x120 graphs."""
+    from oracle import mpn_oracle as orc
+
+    threads = min(16, os.cpu_count() or 1)  # the box's CPU share for one GPU is 16
+    torch.set_num_threads(threads)
+    g = syn.grid_batch(num_graphs=args.cpu_graphs, nx=args.nx, ny=args.ny)
+    ocfg = dict(cfg, in_node_features=4, in_edge_features=2, embedding=None)
+    e = int(g.edge_index.shape[1])
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        orc.supervised_mpn_forward(state_dict, ocfg, g.x, g.edge_attr, g.edge_index, g.mask_output)
+        dt = time.perf_counter() - t0
+    return {"value": e / dt, "unit": "edges/s", "cores": threads, "kind": "port",
+            "sample": f"{args.cpu_graphs} of the {args.nx}x{args.ny} graphs (E={e}), one forward, {dt:.1f} s, torch CPU fp32"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=dev)
+
+    # ---- network: BASELINE config 5 (latent 128, 10 MP steps, inner residual + inner LN, leakyrelu) ----
+    torch.manual_seed(0)
+    cfg = default_architecture(latent_dimension=args.latent, num_steps=args.mp_steps)
+    example = syn.GraphBatch(x=torch.zeros(1, 4), edge_attr=torch.zeros(1, 2))
+    model = SupervisedMPN(cfg, example).eval()
+    state_dict = {k: v.clone() for k, v in model.state_dict().items()}
+    model = model.to(dev)
+
+    # ---- data: synthetic mesh-graph batch, resident in HBM ----
+    g = syn.grid_batch(num_graphs=args.graphs, nx=args.nx, ny=args.ny, seed=1234 + (rank if args.scaling == "weak" else 0))
+    if args.scaling == "strong" and world > 1:
+        g = sharding.shard_batch(g, rank, world)
+    gd = g.to(dev)
+    n, e = int(gd.x.shape[0]), int(gd.edge_index.shape[1])
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    gd.amber_csr = csr_mod.build_csr(gd.edge_index, n)  # once per mesh, outside the timed region
+    torch.cuda.synchronize(dev)
+    csr_ms = (time.perf_counter() - t0) * 1e3
+
+    def step():
+        with torch.no_grad():
+            return model(gd)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    assert torch.isfinite(out).all()
+
+    edges_done = torch.tensor([float(e) * args.steps], device=dev, dtype=torch.float64)
+    t_max = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if dist is not None:
+        dist.all_reduce(edges_done, op=dist.ReduceOp.SUM)
+        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+    total_edges, t = float(edges_done.item()), float(t_max.item())
+
+    # ---- per-kernel device time, measured live with HIP events on the launch stream (rank 0) ----
+    roofline = roofline_hbm = kernels = cpu = None
+    if rank == 0:
+        L, S = args.latent, args.mp_steps
+        desc = engine.make_desc(has_head=True, decoder_layers=2, decoder_activation="leakyrelu", decoder_norm=None,
+                                **model.mpn.desc_kwargs())
+        pieces, _ = model.decoder_mlp.param_list(single_row=False)
+        flat, packed = engine.PackedParams().get(desc, model.mpn.param_list() + pieces + [model.readout.weight, model.readout.bias])
+        ws = engine.workspace(desc, n, e, dev)
+        reps = max(1, min(3, args.steps))
+        ms = [0.0] * 4
+        cnt = [0] * 4
+        for _ in range(reps):
+            _, _, _, m, c = engine.forward(desc, flat, packed, gd.x, gd.edge_attr, gd.amber_csr, want_node=False, want_edge=False,
+                                           out_index=None, n_out=n, ws=ws, timed=True)
+            ms = [a + b for a, b in zip(ms, m)]
+            cnt = [a + b for a, b in zip(cnt, c)]
+        edge_ms = ms[1] / max(cnt[1], 1)   # average duration of one edge-kernel launch
+        node_ms = ms[2] / max(cnt[2], 1)
+        kernels = {"embed_ms_per_forward": ms[0] / reps, "edge_ms_per_launch": edge_ms, "node_ms_per_launch": node_ms,
+                   "edge_launches_per_forward": cnt[1] // reps, "node_launches_per_forward": cnt[2] // reps,
+                   "device_ms_per_forward": sum(ms) / reps, "csr_build_ms_once_per_mesh": csr_ms}
+        # Dominant kernel = edge_kernel<L>.  Algorithmic work per launch (stated in DESIGN.md):
+        #   bytes: E * (16 L + 8): read e, gather two node rows, write e', two int32 indices; the last of the S
+        #          launches writes no e' (E * (12 L + 8)), so the average launch moves E * ((16 - 4/S) L + 8) bytes
+        #   flops: E * 4 L^2 in the weight-split form the kernel implements (direct form: E * 8 L^2)
+        bytes_per_launch = e * ((16.0 - 4.0 / S) * L + 8.0)
+        flops_per_launch = e * 4.0 * L * L
+        ach_tf = flops_per_launch / (edge_ms * 1e-3) / 1e12
+        ach_gbs = bytes_per_launch / (edge_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(REPO, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("edge_kernel_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {"kernel": f"edge_kernel<{L}>", "bound": "mfma", "achieved": ach_tf, "peak": FP32_MFMA_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": ach_tf / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                    "flops_form": "weight-split E*4L^2 (direct form E*8L^2 = 2x)", "avg_launch_ms": edge_ms}
+        roofline_hbm = {"kernel": f"edge_kernel<{L}>", "bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": ach_gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": bytes_per_launch}
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(cfg, state_dict, args)
+
+    if rank == 0:
+        value = total_edges / t
+        bytes_fwd = e * (16 * args.latent + 8) * args.mp_steps + n * 8 * args.latent * args.mp_steps \
+            + e * (4 * 2 + 4 * args.latent) + n * (4 * 4 + 4 * args.latent) + n * (4 * args.latent + 4)
+        line = {
+            "metric": "mpn_forward_edges_per_sec", "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": t / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE config 5: disjoint batch of {args.graphs} triangulated {args.nx}x{args.ny} grids per "
+                                   f"{'GPU' if args.scaling == 'weak' else 'job'}, N={n} E={e} on rank 0, F_n=4 F_e=2, latent {args.latent}, "
+                                   f"{args.mp_steps} MP steps, inner residual + inner LayerNorm, leakyrelu, decoder + readout",
+                       "global_edges_per_step": total_edges / args.steps, "parallelism": f"graph-wise dp{world}, no collective"},
+            "edge_steps_per_sec": value * args.mp_steps,
+            "hbm_roofline_frac_whole_forward": (bytes_fwd / (t / args.steps)) / (HBM_PEAK_GBS * 1e9) if world == 1 else None,
+            "roofline": roofline, "roofline_hbm": roofline_hbm, "kernels": kernels, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,168 @@
+"""CPU tests of the host side: module mirrors (names, state_dict layout, errors), parameter flattening order,
+synthetic generator, graph-wise sharding incl. a world_size-2 gloo run with the oracle as the compute function."""
+import ctypes as C
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from amber_amd import _lib, engine, sharding, synthetic as syn
+from amber_amd.architecture.supervised_mpn import SupervisedMPN
+from amber_amd.config import AttrDict, default_architecture
+from amber_amd.mpn.get_message_passing_base import get_mpn, get_mpn_from_graph
+from conftest import golden_cases, load_golden
+from oracle import mpn_oracle as orc
+
+
+def test_state_dict_names_match_the_reference_checkpoints():
+    """Every golden fixture stores the reference's own state_dict: it must load with strict=True."""
+    for name in golden_cases():
+        cfg, params, d = load_golden(name)
+        model = SupervisedMPN(AttrDict(cfg), syn.GraphBatch(x=d["x"], edge_attr=d["edge_attr"]))
+        assert sorted(model.state_dict().keys()) == sorted(params.keys()), name
+        model.load_state_dict(params, strict=True)
+        for k, v in model.state_dict().items():
+            assert v.shape == params[k].shape, (name, k)
+
+
+def test_flat_parameter_order_and_count():
+    cfg, params, d = load_golden("debug_L64_s2")
+    model = SupervisedMPN(AttrDict(cfg), syn.GraphBatch(x=d["x"], edge_attr=d["edge_attr"]))
+    model.load_state_dict(params)
+    tensors = model.mpn.param_list()
+    desc = engine.make_desc(**model.mpn.desc_kwargs())
+    lib = _lib.load()
+    assert sum(t.numel() for t in tensors) == lib.amber_mpn_param_floats(C.byref(desc)) == 58944
+    # order: node embedding W, b; edge embedding W, b; step 0 edge MLP W0 [L,3L] ...
+    assert tensors[0].shape == (64, 5) and tensors[2].shape == (64, 2) and tensors[4].shape == (64, 192)
+    assert torch.equal(tensors[4], params["mpn.message_passing_stack._message_passing_steps.0.edge_module._mlp.mlp_layers.0.weight"])
+    assert tensors[8].shape == (64, 128)  # node MLP first layer [L, 2L]
+    # LayerNorm params come edge first, then node
+    assert torch.equal(tensors[12], params["mpn.message_passing_stack._message_passing_steps.0._edge_layer_norms.weight"])
+    assert torch.equal(tensors[14], params["mpn.message_passing_stack._message_passing_steps.0._node_layer_norms.weight"])
+
+
+def test_decoder_batchnorm_folding_and_module_indices():
+    cfg = default_architecture(latent_dimension=32, num_steps=1)
+    cfg["decoder"]["regularization"]["latent_normalization"] = "batch"
+    cfg["decoder"]["regularization"]["dropout"] = 0.5
+    model = SupervisedMPN(cfg, syn.GraphBatch(x=torch.zeros(1, 3), edge_attr=torch.zeros(1, 2))).eval()
+    keys = list(model.decoder_mlp.state_dict().keys())
+    # Linear(0) act(1) BN(2) Dropout(3) Linear(4) ...: the reference's ModuleList indices
+    assert "mlp_layers.0.weight" in keys and "mlp_layers.2.running_mean" in keys and "mlp_layers.4.weight" in keys
+    bn = model.decoder_mlp.mlp_layers[2]
+    with torch.no_grad():
+        bn.running_mean.uniform_(-1, 1)
+        bn.running_var.uniform_(0.5, 2)
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-1, 1)
+    pieces, sources = model.decoder_mlp.param_list(single_row=False)
+    x = torch.randn(5, 32)
+    assert torch.allclose(x * pieces[2] + pieces[3], bn(x), atol=1e-6)
+    ident, _ = model.decoder_mlp.param_list(single_row=True)  # SaveBatchnorm1d passes single rows through
+    assert torch.equal(ident[2], torch.ones(32)) and torch.equal(ident[3], torch.zeros(32))
+    assert len(sources) == 2 * (2 + 4)
+
+
+def test_factories_and_error_behaviour():
+    base_cfg = default_architecture(latent_dimension=32, num_steps=2)
+    g = syn.grid_batch(num_graphs=1, nx=4, ny=4, in_node_features=6, in_edge_features=3)
+    mpn = get_mpn_from_graph(example_graph=g, latent_dimension=32, base_config=base_cfg)
+    assert mpn.input_embeddings.node_input_embedding.in_features == 6
+    assert mpn.input_embeddings.edge_input_embedding.in_features == 3
+    assert mpn.message_passing_stack.num_steps == 2
+    with pytest.raises(AssertionError, match="May either provide feature dimensions as int or Dict"):
+        get_mpn(in_node_features=3, in_edge_features={"a": 1}, latent_dimension=32, base_config=base_cfg)
+    with pytest.raises(ValueError, match="Unknown output_type"):
+        from amber_amd.mpn.message_passing_base import MessagePassingBase
+
+        MessagePassingBase(in_node_features=1, in_edge_features=1, latent_dimension=32, stack_config=base_cfg["stack"],
+                           embedding_config=None, output_type="tensor")
+    # no CPU path: the product fails loudly instead of falling back
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        mpn.eval()(g)
+    const = get_mpn(in_node_features=0, in_edge_features=2, latent_dimension=32, base_config=base_cfg)
+    assert list(const.input_embeddings.node_input_embedding.state_dict().keys()) == ["embedding.bias"]
+
+
+def test_synthetic_batch_matches_baseline_config5_counts():
+    el = syn.directed_mesh_edges(syn.grid_triangulation_edges(120, 120), 14400)
+    assert el.shape == (2, 99842)
+    assert np.array_equal(el[:, -14400:], np.stack([np.arange(14400)] * 2))  # self edges last
+    m = syn.grid_triangulation_edges(120, 120).shape[1]
+    assert m == 42721 and np.array_equal(el[0, :m], el[1, m:2 * m])  # both directions, reference order
+    g = syn.grid_batch(num_graphs=3, nx=12, ny=10)
+    assert g.edge_index.max() == g.x.shape[0] - 1 and g.ptr.tolist() == [0, 120, 240, 360]
+    assert float(g.x.abs().max()) <= 20.0
+
+
+def test_partition_is_contiguous_balanced_and_complete():
+    rng = np.random.default_rng(0)
+    w = rng.integers(1000, 200000, size=100)
+    for parts in (1, 2, 3, 8):
+        spans = sharding.partition_contiguous(w, parts)
+        assert spans[0][0] == 0 and spans[-1][1] == 100
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        loads = [w[lo:hi].sum() for lo, hi in spans]
+        assert max(loads) <= w.sum() / parts + w.max()
+    eq = sharding.partition_contiguous([114242] * 100, 8)
+    assert sorted(hi - lo for lo, hi in eq) == [12, 12, 12, 12, 13, 13, 13, 13]  # <= 4 % imbalance at 8 GPUs
+    assert sharding.partition_contiguous([5, 5], 4)[-1][1] == 2  # fewer graphs than ranks: empty shards allowed
+
+
+def test_shard_batch_rebases_indices_and_covers_everything():
+    rng = np.random.default_rng(3)
+    parts = [syn.hierarchical_graph(6, 5, 2, 2, rng), syn.hierarchical_graph(4, 4, 2, 1, rng), syn.hierarchical_graph(5, 3, 1, 2, rng)]
+    g = syn.make_batch([p[0] for p in parts], [p[1] for p in parts], 4, 2, mask_outputs=[p[2] for p in parts])
+    shards = [sharding.shard_batch(g, r, 2) for r in range(2)]
+    assert sum(s.x.shape[0] for s in shards) == g.x.shape[0]
+    assert sum(s.edge_index.shape[1] for s in shards) == g.edge_index.shape[1]
+    for s in shards:
+        if s.edge_index.numel():
+            assert int(s.edge_index.min()) >= 0 and int(s.edge_index.max()) < s.x.shape[0]
+        assert int(s.batch.min()) == 0
+    # without ptr / edge_ptr the sizes are recovered from the batch vector
+    g2 = syn.GraphBatch(x=g.x, edge_attr=g.edge_attr, edge_index=g.edge_index, batch=g.batch, mask_output=g.mask_output)
+    s2 = sharding.shard_batch(g2, 1, 2)
+    assert torch.equal(s2.edge_index, shards[1].edge_index) and torch.equal(s2.x, shards[1].x)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, name, ret):
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg, params, d = load_golden(name)
+    g = syn.GraphBatch(x=d["x"], edge_attr=d["edge_attr"], edge_index=d["edge_index"], batch=d["batch"], ptr=d["ptr"],
+                       mask_output=d["mask_output"])
+
+    def oracle_forward(sub):  # the checker stands in for the device forward: this test is about the sharding logic
+        return orc.supervised_mpn_forward(params, cfg, sub.x, sub.edge_attr, sub.edge_index, sub.mask_output)
+
+    out = sharding.sharded_forward(oracle_forward, g, rank, world)
+    if rank == 0:
+        ret["out"] = out.clone()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["hier_L64_s3", "debug_L64_s2"])
+def test_world_size_2_sharded_forward_equals_unsharded(name):
+    """Graph-wise sharding over 2 gloo ranks reproduces the unsharded result (disjoint-union invariance)."""
+    cfg, params, d = load_golden(name)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(2, _free_port(), name, ret), nprocs=2, join=True)
+    want = d["out_sizing"]
+    got = ret["out"]
+    assert got.shape == want.shape
+    assert float((got - want).abs().max() / want.abs().max()) <= 2e-6
