@@ -76,7 +76,8 @@ int validate(const AmberMpnDesc* d) {
       return fail(AMBER_ERR_UNSUPPORTED, "decoder activation id %d", d->decoder_activation);
     if (d->decoder_norm < 0 || d->decoder_norm > 2) return fail(AMBER_ERR_INVALID_ARGUMENT, "bad decoder_norm");
   }
-  if (d->precision != AMBER_PREC_FP32) return fail(AMBER_ERR_UNSUPPORTED, "precision id %d", d->precision);
+  if (d->precision != AMBER_PREC_FP32 && d->precision != AMBER_PREC_F16X2)
+    return fail(AMBER_ERR_UNSUPPORTED, "precision id %d", d->precision);
   if (!(d->ln_eps > 0.f)) return fail(AMBER_ERR_INVALID_ARGUMENT, "ln_eps must be > 0");
   return AMBER_OK;
 }
@@ -108,11 +109,11 @@ Layout build_layout(const AmberMpnDesc& d) {
         if (pack_first)
           for (int cb = 0; cb < col_blocks; ++cb) {
             m.PW[0][cb] = pk;
-            pk += L * L;
+            pk += L * L + kPackedHeader;
           }
       } else {
         m.PW[l][0] = pk;
-        pk += L * L;
+        pk += L * L + kPackedHeader;
       }
     }
   };
@@ -172,7 +173,7 @@ struct Workspace {
 };
 Workspace carve(const AmberMpnDesc& d, int64_t N, int64_t E, void* base) {
   const size_t L = static_cast<size_t>(d.latent);
-  const size_t T = static_cast<size_t>(cdiv(E, kTile));
+  const size_t T = static_cast<size_t>(cdiv(E, 16));  // finest reduction tile (edge_kernel_h); edge_kernel uses every other slot
   const size_t nb = align256(sizeof(float) * static_cast<size_t>(N) * L);
   const size_t ebytes = align256(sizeof(float) * static_cast<size_t>(E) * L);
   const size_t tb = align256(sizeof(float) * T * L);
@@ -210,32 +211,50 @@ struct Timer {
     if (!on) return;
     Rec r;
     r.cls = cls;
-    hipEventCreate(&r.a);
-    hipEventCreate(&r.b);
-    hipEventRecord(r.a, s);
+    (void)hipEventCreate(&r.a);
+    (void)hipEventCreate(&r.b);
+    (void)hipEventRecord(r.a, s);
     recs.push_back(r);
   }
   void end() {
     if (!on) return;
-    hipEventRecord(recs.back().b, s);
+    (void)hipEventRecord(recs.back().b, s);
   }
   void collect(float* ms, int32_t* launches) {
     for (int i = 0; i < AMBER_MPN_NUM_KERNEL_CLASSES; ++i) {
       ms[i] = 0.f;
       if (launches) launches[i] = 0;
     }
-    hipStreamSynchronize(s);
+    (void)hipStreamSynchronize(s);
     for (auto& r : recs) {
       float t = 0.f;
-      hipEventElapsedTime(&t, r.a, r.b);
+      (void)hipEventElapsedTime(&t, r.a, r.b);
       ms[r.cls] += t;
       if (launches) launches[r.cls] += 1;
-      hipEventDestroy(r.a);
-      hipEventDestroy(r.b);
+      (void)hipEventDestroy(r.a);
+      (void)hipEventDestroy(r.b);
     }
     recs.clear();
   }
 };
+
+bool use_fast_edge(const AmberMpnDesc& d) {
+  return d.precision == AMBER_PREC_F16X2 && edge_fast_supported(d.latent, d.mlp_layers, d.activation, d.residual, d.layer_norm);
+}
+int device_cus() {
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 256;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return 256;
+  return cus;
+}
+hipError_t run_edge(const AmberMpnDesc& d, EdgeArgs& ea, hipStream_t s) {
+  if (use_fast_edge(d)) {
+    ea.red_shift = 4;
+    return launch_edge_h(d.latent, ea, device_cus(), s);
+  }
+  ea.red_shift = 5;
+  return launch_edge(d.latent, ea, s);
+}
 
 // ---------------------------------------------------------------------------------------------------
 // argument builders
@@ -261,6 +280,7 @@ void fill_node_update(NodeArgs& a, const AmberMpnDesc& d, const Layout& lay, int
   a.nl = d.mlp_layers;
   a.act = d.activation;
   for (int l = 1; l < d.mlp_layers; ++l) a.layers[l] = DenseLayer{packed + m.PW[l][0], params + m.B[l], nullptr, nullptr};
+  a.red_shift = use_fast_edge(d) ? 4 : 5;
   a.residual = d.residual;
   a.layer_norm = d.layer_norm;
   a.gamma = d.layer_norm != AMBER_MODE_NONE ? params + lay.ng[step] : nullptr;
@@ -398,7 +418,7 @@ int forward_impl(const AmberMpnDesc* desc, const float* params, const float* pac
     ea.write_e = last ? 0 : 1;  // after the last step only the aggregate (and out_edge, if asked for) is needed
     ea.out_edge = last ? out_edge : nullptr;
     tm.begin(AMBER_KC_EDGE);
-    hipError_t e = launch_edge(L, ea, s);
+    hipError_t e = run_edge(d, ea, s);
     tm.end();
     HIP_TRY(e, "edge kernel");
 
@@ -452,16 +472,20 @@ int amber_mpn_pack_weights(const AmberMpnDesc* desc, const float* params, float*
   const Layout lay = build_layout(*desc);
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int L = desc->latent;
-  auto pack_mlp = [&](const MlpLayout& m, int blocks0) -> hipError_t {
+  // `split_from`: first column block of layer 0 that the f16x2 edge kernel consumes (3 = none); its later
+  // layers are consumed by the same kernel.  Everything else stays in the exact fp32 operand format.
+  auto pack_mlp = [&](const MlpLayout& m, int blocks0, int split_from = 3) -> hipError_t {
     for (int l = 0; l < m.layers; ++l) {
       if (l == 0) {
         for (int cb = 0; cb < blocks0; ++cb)
           if (m.PW[0][cb] >= 0) {
-            hipError_t e = launch_pack(L, params + m.W[0], m.in_cols, cb * L, packed + m.PW[0][cb], s);
+            hipError_t e = cb >= split_from ? launch_pack_h(L, params + m.W[0], m.in_cols, cb * L, packed + m.PW[0][cb], s)
+                                            : launch_pack(L, params + m.W[0], m.in_cols, cb * L, packed + m.PW[0][cb], s);
             if (e != hipSuccess) return e;
           }
       } else if (m.PW[l][0] >= 0) {
-        hipError_t e = launch_pack(L, params + m.W[l], L, 0, packed + m.PW[l][0], s);
+        hipError_t e = split_from < 3 ? launch_pack_h(L, params + m.W[l], L, 0, packed + m.PW[l][0], s)
+                                      : launch_pack(L, params + m.W[l], L, 0, packed + m.PW[l][0], s);
         if (e != hipSuccess) return e;
       }
     }
@@ -470,7 +494,7 @@ int amber_mpn_pack_weights(const AmberMpnDesc* desc, const float* params, float*
   HIP_TRY(pack_mlp(lay.node_embed, 0), "pack node embedding");
   HIP_TRY(pack_mlp(lay.edge_embed, 0), "pack edge embedding");
   for (int st = 0; st < desc->num_steps; ++st) {
-    HIP_TRY(pack_mlp(lay.edge[st], 3), "pack edge MLP");
+    HIP_TRY(pack_mlp(lay.edge[st], 3, use_fast_edge(*desc) ? 2 : 3), "pack edge MLP");
     HIP_TRY(pack_mlp(lay.node[st], 2), "pack node MLP");
   }
   if (desc->has_head) HIP_TRY(pack_mlp(lay.dec, 1), "pack decoder");
@@ -587,7 +611,7 @@ int amber_mpn_block(const AmberMpnDesc* desc, const float* params, const float* 
   ea.head = w.head;
   ea.tail = w.tail;
   ea.write_e = 1;
-  HIP_TRY(launch_edge(L, ea, s), "edge kernel");
+  HIP_TRY(run_edge(*desc, ea, s), "edge kernel");
   NodeArgs na{};
   na.N = num_nodes;
   na.x_in = x_latent;

@@ -1,0 +1,316 @@
+// Split-precision ("f16x2") edge kernel: the same wave-tile chain as edge_kernel<L> (mpn_kernels.hip), with every
+// fp32 contraction carried out on the fp16 matrix pipe at fp32-grade accuracy.
+//
+// Both operands are split into two fp16 terms, x = x_hi + x_lo (22 significant bits together), and three MFMAs
+// (v_mfma_f32_32x32x16_f16: hi*hi, hi*lo, lo*hi, fp32 accumulate) replace the eight v_mfma_f32_32x32x2_f32 of the
+// exact path for the same 16-deep k-step; the dropped lo*lo term is 2^-22 relative.  fp16's narrow exponent range is
+// handled by exact power-of-two scaling: every weight matrix is scaled at pack time so that max|W| lies in
+// [2^14, 2^15), every tile row is scaled per MFMA column (= per lane, so it is free in this layout) by its own
+// max|x|, and the accumulator column is multiplied by the inverse (also a power of two) afterwards.
+//
+// Structure: persistent workgroups of 8 waves (2 per SIMD) keep all layer weights of the edge MLP in LDS
+// (L = 128: 2 x 64 KB) and walk the CSR-ordered edge tiles; each wave owns a tile end to end, so there is no
+// workgroup barrier in the loop.  The epilogue stages 32 features at a time through a 4 KB per-wave LDS window
+// (XOR-swizzled 16-byte slots): per-destination sums by the two half-waves over 16 edges each (partial sums are
+// therefore kept per 16-edge reduction tile), then whole-128-byte row-piece stores.
+#include "mpn_tile.h"
+
+namespace amber {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+constexpr int kFastWaves = 8;
+constexpr int kFastBlock = 64 * kFastWaves;
+constexpr int kFastStageBytes = 4096;  // per wave: 32 rows x 32 features fp32
+
+DEVINL void wave_sync() {
+  // LDS instructions of one wave execute in order; this only stops the compiler from moving LDS accesses of
+  // different lanes' data across the hand-over point.
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+constexpr int kMinScaleExp = 127 - 24;
+
+// power-of-two scale that brings max|row| into [2^14, 2^15), and its inverse
+template <int L>
+DEVINL void tile_row_scale(const Tile<L>& t, float& scale, float& inv) {
+  float m0 = 0.f, m1 = 0.f;
+#pragma unroll
+  for (int fb = 0; fb < L / 32; ++fb)
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) {
+      m0 = fmaxf(m0, fabsf(t.a[fb][i]));
+      m1 = fmaxf(m1, fabsf(t.a[fb][i + 1]));
+    }
+  float m = fmaxf(m0, m1);
+  m = fmaxf(m, __shfl_xor(m, 32));
+  int ex = static_cast<int>((__float_as_uint(m) >> 23) & 0xffu);
+  ex = ex < kMinScaleExp ? kMinScaleExp : ex;  // rows below 2^-24 keep a bounded scale (no overflow of scaled biases)
+  scale = __uint_as_float(static_cast<unsigned>(268 - ex) << 23);
+  inv = __uint_as_float(static_cast<unsigned>(ex - 14) << 23);
+}
+
+// acc += (W * scale_w) * (in * scale), W pre-split and pre-tiled in LDS: [k-step s][fb][hi|lo][lane] x 16 B
+template <int L>
+DEVINL void tile_gemm_h(Tile<L>& acc, const unsigned char* wl, const Tile<L>& in, float scale, int lane) {
+  constexpr int NFB = L / 32, NS = L / 16;
+  const half8* w = reinterpret_cast<const half8*>(wl) + lane;
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    half8 bh, bl;
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+      const int j = 2 * s + (jj >> 2), t = jj & 3;
+      const float xs = in.a[j >> 2][(j & 3) * 4 + t] * scale;
+      const _Float16 hi = static_cast<_Float16>(xs);
+      bh[jj] = hi;
+      bl[jj] = static_cast<_Float16>(xs - static_cast<float>(hi));
+    }
+    half8 ah[NFB], al[NFB];
+#pragma unroll
+    for (int fb = 0; fb < NFB; ++fb) {
+      ah[fb] = w[((s * NFB + fb) * 2 + 0) * 64];
+      al[fb] = w[((s * NFB + fb) * 2 + 1) * 64];
+    }
+#pragma unroll
+    for (int fb = 0; fb < NFB; ++fb) acc.a[fb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[fb], bh, acc.a[fb], 0, 0, 0);
+#pragma unroll
+    for (int fb = 0; fb < NFB; ++fb) acc.a[fb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[fb], bl, acc.a[fb], 0, 0, 0);
+#pragma unroll
+    for (int fb = 0; fb < NFB; ++fb) acc.a[fb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[fb], bh, acc.a[fb], 0, 0, 0);
+  }
+}
+
+// t *= factor (a power of two: exact)
+template <int L>
+DEVINL void tile_scale(Tile<L>& t, float factor) {
+#pragma unroll
+  for (int fb = 0; fb < L / 32; ++fb) t.a[fb] = t.a[fb] * factor;
+}
+
+template <int L>
+DEVINL void tile_act_fast(Tile<L>& t, int act) {
+  const float slope = act == AMBER_ACT_LEAKYRELU ? 0.01f : 0.f;
+#pragma unroll
+  for (int fb = 0; fb < L / 32; ++fb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float v = t.a[fb][i];
+      t.a[fb][i] = v > 0.f ? v : slope * v;
+    }
+}
+
+template <int L>
+__global__ __launch_bounds__(kFastBlock) void edge_kernel_h(const EdgeArgs a, const int64_t ntiles) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int MAT_BYTES = L * L * 4;
+  constexpr int NFB = L / 32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 31, h = lane >> 5;
+
+  // all layer weights (hi/lo fp16, MFMA operand order) into LDS, once per workgroup
+  for (int m = 0; m < a.nl; ++m) {
+    const f32x4* src = reinterpret_cast<const f32x4*>(m == 0 ? a.w0e : a.layers[m].w);
+    f32x4* dst = reinterpret_cast<f32x4*>(smem + m * MAT_BYTES);
+    for (int i = tid; i < MAT_BYTES / 16; i += kFastBlock) dst[i] = src[i];
+  }
+  __syncthreads();
+  float* stage = reinterpret_cast<float*>(smem + a.nl * MAT_BYTES + wave * kFastStageBytes);
+  const float wsinv0 = a.w0e[L * L], wscale0 = a.w0e[L * L + 1];  // pack-time power-of-two weight scale (matrix header)
+
+  // XCD-aware persistent schedule: blocks b, b+8, ... share an XCD (round-robin dispatch); each XCD walks one
+  // contiguous eighth of the tiles with its waves side by side, so gathered P_s rows are shared in that L2.
+  const int64_t xcd = blockIdx.x & 7, local = blockIdx.x >> 3, bpx = gridDim.x >> 3;
+  const int64_t tiles_per_xcd = (ntiles + 7) >> 3;
+  const int64_t t_begin = xcd * tiles_per_xcd;
+  const int64_t t_end = t_begin + tiles_per_xcd < ntiles ? t_begin + tiles_per_xcd : ntiles;
+
+  for (int64_t tile = t_begin + local * kFastWaves + wave; tile < t_end; tile += bpx * kFastWaves) {
+    const int64_t p0 = tile * kTile;
+    const int nvalid = (a.E - p0) < kTile ? static_cast<int>(a.E - p0) : kTile;  // >= 1: tile < ntiles
+    int64_t p = p0 + c;
+    if (p > a.E - 1) p = a.E - 1;
+    const int s = a.src[p], d = a.dst[p];
+
+    // The accumulator starts from the gathered first-layer terms (resp. the bias) moved into the scaled domain
+    // (x 2^k, exact), the MFMAs add the scaled products, one multiply by 2^-k brings the sum back.
+    Tile<L> acc;
+    float scale, inv;
+    {
+      Tile<L> ein;
+      tile_load_row<L>(ein, a.e, p, h);
+      tile_load_row<L>(acc, a.Ps, s, h);
+      tile_add_row<L>(acc, a.Pd, d, h);
+      tile_row_scale<L>(ein, scale, inv);
+      tile_scale<L>(acc, scale * wscale0);
+      tile_gemm_h<L>(acc, smem, ein, scale, lane);
+    }
+    tile_scale<L>(acc, inv * wsinv0);
+    tile_act_fast<L>(acc, a.act);
+#pragma unroll 1
+    for (int l = 1; l < a.nl; ++l) {
+      Tile<L> nxt;
+      tile_row_scale<L>(acc, scale, inv);
+      tile_load_vec<L>(nxt, a.layers[l].b, h);
+      tile_scale<L>(nxt, scale * a.layers[l].w[L * L + 1]);
+      tile_gemm_h<L>(nxt, smem + l * MAT_BYTES, acc, scale, lane);
+      tile_scale<L>(nxt, inv * a.layers[l].w[L * L]);
+      tile_act_fast<L>(nxt, a.act);
+      acc = nxt;
+    }
+    // residual: the old edge rows are read again (they were this wave's own loads a few microseconds ago and sit
+    // in L2) instead of being held in 64 registers across both GEMMs, which keeps the kernel at 2 waves per SIMD
+    if (a.residual == AMBER_MODE_INNER) tile_add_row<L>(acc, a.e, p, h);
+    if (a.layer_norm == AMBER_MODE_INNER) tile_layernorm<L>(acc, a.gamma, a.beta, a.eps, h);
+
+    // ---- epilogue: per-destination sums (half-wave h owns edges 16h .. 16h+15) and row stores, 32 features a pass ----
+    const int f = lane & 31;
+    int dcs[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dcs[i] = __shfl(d, 16 * h + i);
+    int nvh = nvalid - 16 * h;
+    nvh = nvh < 0 ? 0 : (nvh > 16 ? 16 : nvh);
+    const int64_t ph0 = p0 + 16 * h;
+    const int64_t rt = (p0 >> 4) + h;  // 16-edge reduction tile
+    bool sb0 = false, ends_last = false;
+    if (nvh > 0) {
+      const int lastd = __shfl(d, 16 * h + nvh - 1);
+      sb0 = ph0 > static_cast<int64_t>(a.rowptr[dcs[0]]);
+      ends_last = (ph0 + nvh) == static_cast<int64_t>(a.rowptr[lastd + 1]);
+    }
+#pragma unroll
+    for (int q = 0; q < NFB; ++q) {
+      wave_sync();  // the previous pass's readers are done
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+        *reinterpret_cast<f32x4*>(stage + c * 32 + (((2 * jj + h) ^ (c & 7)) << 2)) = tile_get_chunk<L>(acc, 4 * q + jj);
+      wave_sync();
+      if (nvh > 0) {
+        float sum = 0.f;
+        int cur = dcs[0];
+        bool sb = sb0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          if (i < nvh) {
+            const int dc = dcs[i];
+            if (dc != cur) {
+              float* dstp = sb ? a.head + rt * L : a.agg + static_cast<int64_t>(cur) * L;
+              dstp[32 * q + f] = sum;
+              cur = dc;
+              sb = false;
+              sum = 0.f;
+            }
+            const int row = 16 * h + i;
+            sum += stage[row * 32 + ((((f >> 2) ^ (row & 7)) << 2) | (f & 3))];
+          }
+        }
+        float* dstp = (!sb && ends_last) ? a.agg + static_cast<int64_t>(cur) * L : (sb ? a.head + rt * L : a.tail + rt * L);
+        dstp[32 * q + f] = sum;
+      }
+      if (a.write_e || a.out_edge) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int r = it * 8 + (lane >> 3), slot = lane & 7;
+          const f32x4 v = *reinterpret_cast<const f32x4*>(stage + r * 32 + ((slot ^ (r & 7)) << 2));
+          if (r < nvalid) {
+            if (a.write_e) *reinterpret_cast<f32x4*>(a.e + (p0 + r) * L + 32 * q + 4 * slot) = v;
+            if (a.out_edge) *reinterpret_cast<f32x4*>(a.out_edge + static_cast<int64_t>(a.perm[p0 + r]) * L + 32 * q + 4 * slot) = v;
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// weight packing: absmax -> power-of-two scale -> hi/lo fp16 in MFMA operand order (+ header)
+// ---------------------------------------------------------------------------------------------------
+__global__ void absmax_kernel(const float* __restrict__ W, int ld, int col0, int L, unsigned* __restrict__ out_bits) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= L * L) return;
+  const float v = fabsf(W[static_cast<int64_t>(i / L) * ld + col0 + (i % L)]);
+  atomicMax(out_bits, __float_as_uint(v));  // non-negative floats order like their bit patterns; integer atomic
+}
+
+// out: [s][fb][hi|lo][lane][8 halves]; element jj of lane (h, r) is W[32 fb + r][16 s + 8 (jj >> 2) + 4 h + (jj & 3)];
+// header (8 floats after the L*L*4 body bytes): [0] = inverse scale (read by the kernel), [1] = scale
+template <int L>
+__global__ void pack_h_kernel(const float* __restrict__ W, int ld, int col0, float* __restrict__ out,
+                              const unsigned* __restrict__ absmax_bits) {
+  constexpr int NFB = L / 32, NS = L / 16;
+  int ex = static_cast<int>((*absmax_bits >> 23) & 0xffu);
+  ex = ex < kMinScaleExp ? kMinScaleExp : ex;
+  const float scale = __uint_as_float(static_cast<unsigned>(268 - ex) << 23);
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // (s, fb, lane)
+  if (i == 0) {
+    out[L * L + 0] = __uint_as_float(static_cast<unsigned>(ex - 14) << 23);
+    out[L * L + 1] = scale;
+  }
+  if (i >= NS * NFB * 64) return;
+  const int lane = i & 63, fb = (i >> 6) % NFB, s = (i >> 6) / NFB;
+  const float* src = W + static_cast<int64_t>(32 * fb + (lane & 31)) * ld + col0 + 16 * s + 4 * (lane >> 5);
+  half8 hi, lo;
+#pragma unroll
+  for (int jj = 0; jj < 8; ++jj) {
+    const float ws = src[8 * (jj >> 2) + (jj & 3)] * scale;
+    const _Float16 hh = static_cast<_Float16>(ws);
+    hi[jj] = hh;
+    lo[jj] = static_cast<_Float16>(ws - static_cast<float>(hh));
+  }
+  half8* o = reinterpret_cast<half8*>(out);
+  o[((s * NFB + fb) * 2 + 0) * 64 + lane] = hi;
+  o[((s * NFB + fb) * 2 + 1) * 64 + lane] = lo;
+}
+
+template <int L>
+static hipError_t launch_pack_h_t(const float* W, int ld, int col0, float* out, hipStream_t s) {
+  unsigned* bits = reinterpret_cast<unsigned*>(out + L * L + 4);  // scratch word inside the header
+  hipError_t e = hipMemsetAsync(bits, 0, sizeof(unsigned), s);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(absmax_kernel, dim3((L * L + 255) / 256), dim3(256), 0, s, W, ld, col0, L, bits);
+  hipLaunchKernelGGL(pack_h_kernel<L>, dim3((L / 16 * (L / 32) * 64 + 255) / 256), dim3(256), 0, s, W, ld, col0, out, bits);
+  return hipGetLastError();
+}
+
+hipError_t launch_pack_h(int L, const float* W, int ld, int col0, float* out, hipStream_t s) {
+  switch (L) {
+    case 32: return launch_pack_h_t<32>(W, ld, col0, out, s);
+    case 64: return launch_pack_h_t<64>(W, ld, col0, out, s);
+    case 128: return launch_pack_h_t<128>(W, ld, col0, out, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+size_t edge_fast_lds_bytes(int L, int nl) { return static_cast<size_t>(nl) * L * L * 4 + kFastWaves * kFastStageBytes; }
+
+bool edge_fast_supported(int L, int nl, int act, int residual, int layer_norm) {
+  return (act == AMBER_ACT_RELU || act == AMBER_ACT_LEAKYRELU) && residual != AMBER_MODE_OUTER &&
+         layer_norm != AMBER_MODE_OUTER && edge_fast_lds_bytes(L, nl) <= 160 * 1024;
+}
+
+template <int L>
+static hipError_t launch_edge_h_t(const EdgeArgs& a, int num_cus, hipStream_t s) {
+  const int64_t ntiles = (a.E + kTile - 1) / kTile;
+  if (ntiles == 0) return hipSuccess;
+  const size_t lds = edge_fast_lds_bytes(L, a.nl);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(edge_kernel_h<L>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     static_cast<int>(lds));
+  if (e != hipSuccess) return e;
+  int64_t grid = (num_cus / 8) * 8;  // one persistent workgroup per CU, a multiple of the 8 XCDs
+  if (grid < 8) grid = 8;
+  hipLaunchKernelGGL(edge_kernel_h<L>, dim3(static_cast<unsigned>(grid)), dim3(kFastBlock), lds, s, a, ntiles);
+  return hipGetLastError();
+}
+
+hipError_t launch_edge_h(int L, const EdgeArgs& a, int num_cus, hipStream_t s) {
+  switch (L) {
+    case 32: return launch_edge_h_t<32>(a, num_cus, s);
+    case 64: return launch_edge_h_t<64>(a, num_cus, s);
+    case 128: return launch_edge_h_t<128>(a, num_cus, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace amber

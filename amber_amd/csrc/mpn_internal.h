@@ -42,6 +42,7 @@ struct EdgeArgs {
   float* agg;             // [N,L] sums of rows that lie inside one tile
   float* head;            // [T,L] partial sum of a tile's first row when that row began in an earlier tile
   float* tail;            // [T,L] partial sum of a tile's last row when it began here and continues
+  int32_t red_shift;      // log2 of the reduction tile the partial sums are indexed by (5: edge_kernel, 4: edge_kernel_h)
   int32_t write_e;        // store the updated e (CSR order)
   float* out_edge;        // [E,L] edge_index order, or nullptr
 };
@@ -57,6 +58,7 @@ struct NodeArgs {
   const float* agg;
   const float* head;
   const float* tail;
+  int32_t red_shift;      // log2 of the reduction tile of head / tail (must match the edge kernel that wrote them)
   const float* w0x;       // packed W0[:, 0:L]
   const float* w0a;       // packed W0[:, L:2L]
   const float* b0;
@@ -96,6 +98,11 @@ hipError_t launch_embed(int L, const float* in, int64_t rows, int F, const float
                         int act_or_neg1, float* out, hipStream_t s);
 // re-tile W[L, ld] columns [col0, col0+L) into MFMA operand order
 hipError_t launch_pack(int L, const float* W, int ld, int col0, float* out, hipStream_t s);
+// split-precision (f16x2) path, mpn_fast.hip.  A packed matrix is L*L floats of body + kPackedHeader floats.
+constexpr int kPackedHeader = 8;
+hipError_t launch_pack_h(int L, const float* W, int ld, int col0, float* out, hipStream_t s);
+hipError_t launch_edge_h(int L, const EdgeArgs& a, int num_cus, hipStream_t s);
+bool edge_fast_supported(int L, int nl, int act, int residual, int layer_norm);
 hipError_t launch_segment_mean(const float* vals, const int32_t* rowptr, int64_t N, int L, float* out, hipStream_t s);
 hipError_t launch_permute_rows(const float* in, const int32_t* perm, int64_t rows, int width, int gather, float* out,
                                hipStream_t s);

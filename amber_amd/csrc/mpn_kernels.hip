@@ -21,247 +21,9 @@
 // Aggregation (scatter_mean) is fused into the edge kernel: the tile is staged in LDS and summed
 // sequentially per destination row in CSR order (deterministic, no atomics).  Rows cut by a tile
 // boundary leave partial sums in head/tail buffers that the node kernel adds in tile order.
-#include "mpn_internal.h"
+#include "mpn_tile.h"
 
 namespace amber {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-#define DEVINL __device__ __forceinline__
-
-constexpr int kWavesPerBlock = 4;
-constexpr int kBlock = 64 * kWavesPerBlock;
-
-template <int L>
-struct Tile {
-  f32x16 a[L / 32];
-};
-
-template <int L>
-constexpr int stage_stride() {
-  return L + 4;  // floats; +16 B per row keeps 16-byte alignment and spreads rows over LDS banks
-}
-template <int L>
-constexpr int stage_floats() {
-  return kTile * stage_stride<L>();
-}
-
-// ---------------------------------------------------------------------------------------------------
-// activations (torch defaults)
-// ---------------------------------------------------------------------------------------------------
-DEVINL float act_one(float v, int act) {
-  switch (act) {
-    case AMBER_ACT_RELU:
-      return v > 0.f ? v : 0.f;
-    case AMBER_ACT_LEAKYRELU:
-      return v > 0.f ? v : 0.01f * v;
-    case AMBER_ACT_TANH:
-      return tanhf(v);
-    case AMBER_ACT_ELU:
-      return v > 0.f ? v : expm1f(v);
-    case AMBER_ACT_SILU:
-      return v / (1.f + expf(-v));
-    case AMBER_ACT_MISH: {
-      const float sp = v > 20.f ? v : log1pf(expf(v));  // softplus, threshold 20
-      return v * tanhf(sp);
-    }
-    case AMBER_ACT_GELU:
-      return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
-    default:
-      return v;
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// tile helpers (all loops fully unrolled: register indices must be compile-time constants)
-// ---------------------------------------------------------------------------------------------------
-template <int L>
-DEVINL void tile_set_chunk(Tile<L>& t, int j, f32x4 v) {
-  t.a[j >> 2][(j & 3) * 4 + 0] = v[0];
-  t.a[j >> 2][(j & 3) * 4 + 1] = v[1];
-  t.a[j >> 2][(j & 3) * 4 + 2] = v[2];
-  t.a[j >> 2][(j & 3) * 4 + 3] = v[3];
-}
-template <int L>
-DEVINL f32x4 tile_get_chunk(const Tile<L>& t, int j) {
-  f32x4 v;
-  v[0] = t.a[j >> 2][(j & 3) * 4 + 0];
-  v[1] = t.a[j >> 2][(j & 3) * 4 + 1];
-  v[2] = t.a[j >> 2][(j & 3) * 4 + 2];
-  v[3] = t.a[j >> 2][(j & 3) * 4 + 3];
-  return v;
-}
-
-template <int L>
-DEVINL void tile_zero(Tile<L>& t) {
-#pragma unroll
-  for (int fb = 0; fb < L / 32; ++fb)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) t.a[fb][i] = 0.f;
-}
-
-// t = rows[row][:]  (this lane's chunks of one row-major row of L floats)
-template <int L>
-DEVINL void tile_load_row(Tile<L>& t, const float* __restrict__ base, int64_t row, int h) {
-  const f32x4* p = reinterpret_cast<const f32x4*>(base + row * L) + h;
-#pragma unroll
-  for (int j = 0; j < L / 8; ++j) tile_set_chunk<L>(t, j, p[2 * j]);
-}
-template <int L>
-DEVINL void tile_add_row(Tile<L>& t, const float* __restrict__ base, int64_t row, int h) {
-  const f32x4* p = reinterpret_cast<const f32x4*>(base + row * L) + h;
-#pragma unroll
-  for (int j = 0; j < L / 8; ++j) tile_set_chunk<L>(t, j, tile_get_chunk<L>(t, j) + p[2 * j]);
-}
-// t[c][f] = vec[f] for every row (bias as initial accumulator)
-template <int L>
-DEVINL void tile_load_vec(Tile<L>& t, const float* __restrict__ vec, int h) {
-  const f32x4* p = reinterpret_cast<const f32x4*>(vec) + h;
-#pragma unroll
-  for (int j = 0; j < L / 8; ++j) tile_set_chunk<L>(t, j, p[2 * j]);
-}
-template <int L>
-DEVINL void tile_add(Tile<L>& t, const Tile<L>& o) {
-#pragma unroll
-  for (int fb = 0; fb < L / 32; ++fb) t.a[fb] += o.a[fb];
-}
-
-// acc += W * in, W an L x L matrix pre-tiled by pack_kernel; exact fp32 MFMA (a k-ordered fmaf chain).
-template <int L>
-DEVINL void tile_gemm(Tile<L>& acc, const float* __restrict__ wpacked, const Tile<L>& in, int lane) {
-  constexpr int NFB = L / 32, NJ = L / 8;
-  const f32x4* __restrict__ w = reinterpret_cast<const f32x4*>(wpacked) + lane;
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    f32x4 wf[NFB];
-#pragma unroll
-    for (int fb = 0; fb < NFB; ++fb) wf[fb] = w[(j * NFB + fb) * 64];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const float b = in.a[j >> 2][(j & 3) * 4 + t];
-#pragma unroll
-      for (int fb = 0; fb < NFB; ++fb) acc.a[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[fb][t], b, acc.a[fb], 0, 0, 0);
-    }
-  }
-}
-
-// LayerNorm over the L features of every row: the row lives in lanes (0, c) and (1, c).
-template <int L>
-DEVINL void tile_layernorm(Tile<L>& t, const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int h) {
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-#pragma unroll
-  for (int fb = 0; fb < L / 32; ++fb)
-#pragma unroll
-    for (int i = 0; i < 16; i += 4) {
-      s0 += t.a[fb][i + 0];
-      s1 += t.a[fb][i + 1];
-      s2 += t.a[fb][i + 2];
-      s3 += t.a[fb][i + 3];
-    }
-  float s = (s0 + s1) + (s2 + s3);
-  s += __shfl_xor(s, 32);
-  const float mean = s * (1.0f / L);
-  s0 = s1 = s2 = s3 = 0.f;
-#pragma unroll
-  for (int fb = 0; fb < L / 32; ++fb)
-#pragma unroll
-    for (int i = 0; i < 16; i += 4) {
-      const float d0 = t.a[fb][i + 0] - mean, d1 = t.a[fb][i + 1] - mean;
-      const float d2 = t.a[fb][i + 2] - mean, d3 = t.a[fb][i + 3] - mean;
-      s0 += d0 * d0;
-      s1 += d1 * d1;
-      s2 += d2 * d2;
-      s3 += d3 * d3;
-    }
-  float q = (s0 + s1) + (s2 + s3);
-  q += __shfl_xor(q, 32);
-  const float rstd = 1.0f / sqrtf(q * (1.0f / L) + eps);
-  const f32x4* g = reinterpret_cast<const f32x4*>(gamma) + h;
-  const f32x4* b = reinterpret_cast<const f32x4*>(beta) + h;
-#pragma unroll
-  for (int j = 0; j < L / 8; ++j) {
-    const f32x4 v = tile_get_chunk<L>(t, j);
-    tile_set_chunk<L>(t, j, (v - mean) * rstd * g[2 * j] + b[2 * j]);
-  }
-}
-// per-feature affine v * p + q (eval-mode BatchNorm folded on the host)
-template <int L>
-DEVINL void tile_affine(Tile<L>& t, const float* __restrict__ p, const float* __restrict__ q, int h) {
-  const f32x4* g = reinterpret_cast<const f32x4*>(p) + h;
-  const f32x4* b = reinterpret_cast<const f32x4*>(q) + h;
-#pragma unroll
-  for (int j = 0; j < L / 8; ++j) tile_set_chunk<L>(t, j, tile_get_chunk<L>(t, j) * g[2 * j] + b[2 * j]);
-}
-
-// tile <-> LDS staging area of the wave, row-major [32][L + 4]
-template <int L>
-DEVINL void tile_stage(float* stage, const Tile<L>& t, int c, int h) {
-  f32x4* p = reinterpret_cast<f32x4*>(stage + c * stage_stride<L>()) + h;
-#pragma unroll
-  for (int j = 0; j < L / 8; ++j) p[2 * j] = tile_get_chunk<L>(t, j);
-}
-template <int L>
-DEVINL void tile_unstage(const float* stage, Tile<L>& t, int c, int h) {
-  const f32x4* p = reinterpret_cast<const f32x4*>(stage + c * stage_stride<L>()) + h;
-#pragma unroll
-  for (int j = 0; j < L / 8; ++j) tile_set_chunk<L>(t, j, p[2 * j]);
-}
-
-// Activation on a tile.  relu / leakyrelu stay in registers; the transcendental ones take a round trip
-// through the wave's LDS staging area so that each math routine is instantiated once (block-uniform branch).
-template <int L>
-DEVINL void tile_act(Tile<L>& t, int act, float* stage, int lane) {
-  if (act == AMBER_ACT_RELU) {
-#pragma unroll
-    for (int fb = 0; fb < L / 32; ++fb)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) t.a[fb][i] = fmaxf(t.a[fb][i], 0.f);
-  } else if (act == AMBER_ACT_LEAKYRELU) {
-#pragma unroll
-    for (int fb = 0; fb < L / 32; ++fb)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const float v = t.a[fb][i];
-        t.a[fb][i] = v > 0.f ? v : 0.01f * v;
-      }
-  } else {
-    const int c = lane & 31, h = lane >> 5;
-    __syncthreads();
-    tile_stage<L>(stage, t, c, h);
-    __syncthreads();
-    for (int i = lane; i < stage_floats<L>(); i += 64) stage[i] = act_one(stage[i], act);
-    __syncthreads();
-    tile_unstage<L>(stage, t, c, h);
-  }
-}
-
-// Store the staged tile as whole rows: out[row(r)][:] = stage[r][:], r < nvalid.  rowmap == nullptr: rows
-// row0 + r; otherwise rows rowmap[row0 + r] (un-permute to edge_index order).
-template <int L>
-DEVINL void stage_store_rows(const float* stage, float* __restrict__ out, int64_t row0, int nvalid,
-                             const int32_t* __restrict__ rowmap, int lane) {
-  constexpr int LPR = L / 4;        // lanes per row (16 B each)
-  constexpr int RPI = 64 / LPR;     // rows per wave instruction
-  const int q = lane % LPR;
-#pragma unroll
-  for (int it = 0; it < kTile / RPI; ++it) {
-    const int r = it * RPI + lane / LPR;
-    if (r < nvalid) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(stage + r * stage_stride<L>() + 4 * q);
-      const int64_t dr = rowmap ? static_cast<int64_t>(rowmap[row0 + r]) : row0 + r;
-      *reinterpret_cast<f32x4*>(out + dr * L + 4 * q) = v;
-    }
-  }
-}
-
-// XCD-aware block remap: blocks b and b + 8 share an XCD (round-robin dispatch), so give each XCD a
-// contiguous range of tiles; neighbouring tiles gather overlapping P_s rows and then share an L2.
-DEVINL int64_t xcd_remap(int64_t bid, int64_t nblk) {
-  const int64_t xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
-  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-}
 
 // ---------------------------------------------------------------------------------------------------
 // edge kernel: K2 (gather), K3 (edge MLP), K4 (residual), K5 (LayerNorm), K6 (segmented sum)
@@ -387,7 +149,7 @@ __global__ __launch_bounds__(kBlock) void node_kernel(const NodeArgs a, const in
     if (deg == 0) {
       tile_zero<L>(g);
     } else {
-      const int t0 = r0 / kTile, t1 = (r1 - 1) / kTile;
+      const int t0 = r0 >> a.red_shift, t1 = (r1 - 1) >> a.red_shift;
       if (t0 == t1) {
         tile_load_row<L>(g, a.agg, n, h);
       } else {

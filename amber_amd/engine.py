@@ -4,6 +4,7 @@ flattening + MFMA re-tiling (cached), workspace, and the compute calls.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -12,11 +13,17 @@ from . import _lib
 from .csr import CSR, _require_cuda
 
 
+PRECISIONS = {"fp32": 0, "f16x2": 1}
+# Precision of the MLP contractions used by the nn.Module mirrors: "fp32" = exact fp32 MFMA everywhere; "f16x2" =
+# fp32-grade split precision in the edge kernel (include/amber_mpn.h, AMBER_PREC_F16X2).  Both meet the 1e-5 bar.
+default_precision = os.environ.get("AMBER_MPN_PRECISION", "f16x2")
+
+
 def make_desc(*, latent: int, num_steps: int, num_step_repeats: int, mlp_layers: int, activation: str,
               residual: Optional[str], layer_norm: Optional[str], in_node_features: int, in_edge_features: int,
               embed_layers: int = 0, embed_activation: str = "leakyrelu", has_head: bool = False,
               decoder_layers: int = 0, decoder_activation: str = "leakyrelu", decoder_norm: Optional[str] = None,
-              ln_eps: float = 1e-5) -> _lib.AmberMpnDesc:
+              ln_eps: float = 1e-5, precision: Optional[str] = None) -> _lib.AmberMpnDesc:
     def lut(table, key, what):
         k = key.lower() if isinstance(key, str) else key
         if k not in table:
@@ -30,7 +37,8 @@ def make_desc(*, latent: int, num_steps: int, num_step_repeats: int, mlp_layers:
         in_edge_features=in_edge_features, embed_layers=embed_layers,
         embed_activation=lut(_lib.ACT, embed_activation, "activation function"), has_head=1 if has_head else 0,
         decoder_layers=decoder_layers, decoder_activation=lut(_lib.ACT, decoder_activation, "activation function"),
-        decoder_norm=lut(_lib.NORM, decoder_norm, "latent_normalization"), precision=0, ln_eps=ln_eps)
+        decoder_norm=lut(_lib.NORM, decoder_norm, "latent_normalization"),
+        precision=lut(PRECISIONS, precision if precision is not None else default_precision, "precision"), ln_eps=ln_eps)
 
 
 class PackedParams:

@@ -27,7 +27,7 @@ extern "C" {
 
 #define AMBER_MPN_ABI_VERSION 1
 #define AMBER_MPN_MAX_MLP_LAYERS 4
-#define AMBER_MPN_TILE 32 /* sorted edges per wave tile; partial-sum buffers are indexed by edge position / TILE */
+#define AMBER_MPN_TILE 32 /* sorted edges (or nodes) per wave tile */
 
 enum {
   AMBER_OK = 0,
@@ -57,7 +57,11 @@ enum { AMBER_NORM_NONE = 0, AMBER_NORM_LAYER = 1, AMBER_NORM_AFFINE = 2 /* Batch
 
 /* precision of the MLP contractions */
 enum {
-  AMBER_PREC_FP32 = 0 /* exact fp32 MFMA (v_mfma_f32_32x32x2_f32), tolerance 1e-5 */
+  AMBER_PREC_FP32 = 0, /* exact fp32 MFMA (v_mfma_f32_32x32x2_f32): a k-ordered fmaf chain */
+  AMBER_PREC_F16X2 = 1 /* fp32-grade split precision: operands as hi + lo fp16 pairs (22 bits) with exact
+                          power-of-two row / matrix scaling, 3 fp16 MFMAs per product, fp32 accumulate; meets the
+                          fp32 tolerance (1e-5).  Used by the edge kernel where the configuration allows it
+                          (relu / leakyrelu, no "outer" modes, weights fit LDS), otherwise the exact path runs. */
 };
 
 /* Static description of the network: the hyper-parameters the reference reads from

@@ -47,8 +47,8 @@ def test_param_count_matches_survey_formula():
     assert lib.amber_mpn_param_floats(C.byref(d)) == 58944
     d = _desc(has_head=True, decoder_layers=2)
     assert lib.amber_mpn_param_floats(C.byref(d)) == 58944 + 2 * (64 * 64 + 64) + 64 + 1
-    # packed: per step 3 + 1 edge matrices, 2 + 1 node matrices; 2 decoder matrices
-    assert lib.amber_mpn_packed_floats(C.byref(d)) == (2 * 7 + 2) * 64 * 64
+    # packed: per step 3 + 1 edge matrices, 2 + 1 node matrices; 2 decoder matrices; each L*L body + 8-float header
+    assert lib.amber_mpn_packed_floats(C.byref(d)) == (2 * 7 + 2) * (64 * 64 + 8)
 
 
 def test_descriptor_validation_reports_errors():
@@ -65,7 +65,7 @@ def test_workspace_size_formula():
     lib = _lib.load()
     d = _desc(latent=128)
     n, e = 1000, 7000
-    tiles = (e + 31) // 32
+    tiles = (e + 15) // 16  # partial-sum slots: one per 16-edge reduction tile
     a256 = lambda b: (b + 255) // 256 * 256  # noqa: E731
     expect = 4 * a256(n * 128 * 4) + 2 * a256(tiles * 128 * 4) + a256(e * 128 * 4) + 256
     assert lib.amber_mpn_workspace_bytes(C.byref(d), n, e) == expect

@@ -20,6 +20,16 @@ pytestmark = pytest.mark.gpu
 FP32_TOL = 1e-5
 
 
+@pytest.fixture(params=["fp32", "f16x2"], autouse=True)
+def precision(request):
+    """Every parity test runs twice: exact fp32 MFMA, and the fp32-grade split-precision (f16x2) edge kernel.
+    Both must meet the fp32 bar of 1e-5."""
+    old = engine.default_precision
+    engine.default_precision = request.param
+    yield request.param
+    engine.default_precision = old
+
+
 def _model_from_golden(cfg, params, data, device):
     example = syn.GraphBatch(x=data["x"], edge_attr=data["edge_attr"])
     model = SupervisedMPN(AttrDict(cfg), example)
