@@ -1,6 +1,7 @@
 // Host side of libamber_mpn.so: parameter layout, workspace carving, launch sequencing, C ABI.
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -249,7 +250,7 @@ int device_cus() {
 }
 hipError_t run_edge(const AmberMpnDesc& d, EdgeArgs& ea, hipStream_t s) {
   if (use_fast_edge(d)) {
-    ea.red_shift = 4;
+    ea.red_shift = 5;
     return launch_edge_h(d.latent, ea, device_cus(), s);
   }
   ea.red_shift = 5;
@@ -280,7 +281,7 @@ void fill_node_update(NodeArgs& a, const AmberMpnDesc& d, const Layout& lay, int
   a.nl = d.mlp_layers;
   a.act = d.activation;
   for (int l = 1; l < d.mlp_layers; ++l) a.layers[l] = DenseLayer{packed + m.PW[l][0], params + m.B[l], nullptr, nullptr};
-  a.red_shift = use_fast_edge(d) ? 4 : 5;
+  a.red_shift = 5;
   a.residual = d.residual;
   a.layer_norm = d.layer_norm;
   a.gamma = d.layer_norm != AMBER_MODE_NONE ? params + lay.ng[step] : nullptr;

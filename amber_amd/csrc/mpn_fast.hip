@@ -8,20 +8,21 @@
 // [2^14, 2^15), every tile row is scaled per MFMA column (= per lane, so it is free in this layout) by its own
 // max|x|, and the accumulator column is multiplied by the inverse (also a power of two) afterwards.
 //
-// Structure: persistent workgroups of 8 waves (2 per SIMD) keep all layer weights of the edge MLP in LDS
-// (L = 128: 2 x 64 KB) and walk the CSR-ordered edge tiles; each wave owns a tile end to end, so there is no
-// workgroup barrier in the loop.  The epilogue stages 32 features at a time through a 4 KB per-wave LDS window
-// (XOR-swizzled 16-byte slots): per-destination sums by the two half-waves over 16 edges each (partial sums are
-// therefore kept per 16-edge reduction tile), then whole-128-byte row-piece stores.
+// Structure: persistent workgroups of 8 waves (two per SIMD, <= 256 registers each) keep all layer weights of the
+// edge MLP in LDS (L = 128: 2 x 64 KB) and walk the CSR-ordered edge tiles; each wave owns a tile end to end, so
+// there is no workgroup barrier in the loop and the two waves of a SIMD overlap each other's memory and MFMA phases.
+// All row traffic is whole 128-byte row pieces, transposed to / from the accumulator layout through a 4 KB
+// per-wave LDS window (XOR-swizzled 16-byte slots); the epilogue sums per destination in CSR order with
+// wave-uniform control flow, 32 features a pass.  (A one-wave-per-SIMD variant with the next tile prefetched into
+// registers was tried: hipcc spilled the landing areas to scratch and it ran 1.6x slower.)
 #include "mpn_tile.h"
 
 namespace amber {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
-constexpr int kFastWaves = 8;
+constexpr int kFastWaves = 8;  // two waves per SIMD (<= 256 registers each) overlap each other's memory and MFMA phases
 constexpr int kFastBlock = 64 * kFastWaves;
-constexpr int kFastStageBytes = 4096;  // per wave: 32 rows x 32 features fp32
 
 DEVINL void wave_sync() {
   // LDS instructions of one wave execute in order; this only stops the compiler from moving LDS accesses of
@@ -98,15 +99,69 @@ DEVINL void tile_act_fast(Tile<L>& t, int act) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const float v = t.a[fb][i];
-      t.a[fb][i] = v > 0.f ? v : slope * v;
+      t.a[fb][i] = fmaxf(v, slope * v);  // slope in [0, 1): max picks v for v > 0 and slope * v otherwise
     }
+}
+
+// Coalesced row traffic.  A lane-per-row 16-byte load touches 32 different rows per wave instruction; instead every
+// wave instruction reads whole row pieces of PF features (PF * 4 bytes, whole 128-byte lines) into a register
+// "landing" area, and the pieces are turned into the accumulator layout PF features at a time through the wave's
+// LDS window (XOR-swizzled 16-byte slots, conflict-free both ways).  Landing areas double as prefetch buffers: the
+// next tile's rows are in flight while the current tile computes.
+template <int L>
+struct Geo {
+  static constexpr int PF = 32;                // features per pass through the LDS window (4 KB per wave)
+  static constexpr int NPASS = L / PF;
+  static constexpr int LPP = PF / 4;           // lanes per row piece
+  static constexpr int RPI = 64 / LPP;         // rows per wave instruction
+  static constexpr int NIT = kTile / RPI;
+  static constexpr int STAGE_FLOATS = kTile * PF;
+};
+template <int L>
+struct RowLanding {
+  f32x4 v[Geo<L>::NPASS][Geo<L>::NIT];
+};
+// lane c (both half-waves) holds the global row index of tile row c
+template <int L>
+DEVINL void rows_issue(RowLanding<L>& ld, const float* __restrict__ base, int rowidx_by_c, int lane) {
+  using G = Geo<L>;
+  const int slot = lane % G::LPP;
+#pragma unroll
+  for (int it = 0; it < G::NIT; ++it) {
+    const int r = it * G::RPI + lane / G::LPP;
+    const int row = __shfl(rowidx_by_c, r);
+    const f32x4* p = reinterpret_cast<const f32x4*>(base + static_cast<int64_t>(row) * L) + slot;
+#pragma unroll
+    for (int ps = 0; ps < G::NPASS; ++ps) ld.v[ps][it] = p[ps * G::LPP];
+  }
+}
+template <int L, bool ADD>
+DEVINL void rows_land(Tile<L>& t, const RowLanding<L>& ld, float* stage, int lane) {
+  using G = Geo<L>;
+  const int c = lane & 31, h = lane >> 5, slot = lane % G::LPP;
+#pragma unroll
+  for (int ps = 0; ps < G::NPASS; ++ps) {
+    wave_sync();
+#pragma unroll
+    for (int it = 0; it < G::NIT; ++it) {
+      const int r = it * G::RPI + lane / G::LPP;
+      *reinterpret_cast<f32x4*>(stage + r * G::PF + ((slot ^ (r & (G::LPP - 1))) << 2)) = ld.v[ps][it];
+    }
+    wave_sync();
+#pragma unroll
+    for (int jj = 0; jj < G::PF / 8; ++jj) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(stage + c * G::PF + (((2 * jj + h) ^ (c & (G::LPP - 1))) << 2));
+      const int j = ps * (G::PF / 8) + jj;
+      tile_set_chunk<L>(t, j, ADD ? tile_get_chunk<L>(t, j) + v : v);
+    }
+  }
 }
 
 template <int L>
 __global__ __launch_bounds__(kFastBlock) void edge_kernel_h(const EdgeArgs a, const int64_t ntiles) {
+  using G = Geo<L>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int MAT_BYTES = L * L * 4;
-  constexpr int NFB = L / 32;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 31, h = lane >> 5;
 
@@ -117,7 +172,7 @@ __global__ __launch_bounds__(kFastBlock) void edge_kernel_h(const EdgeArgs a, co
     for (int i = tid; i < MAT_BYTES / 16; i += kFastBlock) dst[i] = src[i];
   }
   __syncthreads();
-  float* stage = reinterpret_cast<float*>(smem + a.nl * MAT_BYTES + wave * kFastStageBytes);
+  float* stage = reinterpret_cast<float*>(smem + a.nl * MAT_BYTES) + wave * G::STAGE_FLOATS;
   const float wsinv0 = a.w0e[L * L], wscale0 = a.w0e[L * L + 1];  // pack-time power-of-two weight scale (matrix header)
 
   // XCD-aware persistent schedule: blocks b, b+8, ... share an XCD (round-robin dispatch); each XCD walks one
@@ -126,13 +181,34 @@ __global__ __launch_bounds__(kFastBlock) void edge_kernel_h(const EdgeArgs a, co
   const int64_t tiles_per_xcd = (ntiles + 7) >> 3;
   const int64_t t_begin = xcd * tiles_per_xcd;
   const int64_t t_end = t_begin + tiles_per_xcd < ntiles ? t_begin + tiles_per_xcd : ntiles;
+  const int64_t stride = bpx * kFastWaves;
+  int64_t tile = t_begin + local * kFastWaves + wave;
 
-  for (int64_t tile = t_begin + local * kFastWaves + wave; tile < t_end; tile += bpx * kFastWaves) {
+  // the indices of a wave's next two tiles are loaded ahead, so a tile starts with its row loads, not with a
+  // dependent index fetch
+  int s0 = 0, d0 = 0, pc0 = 0, s1 = 0, d1 = 0, pc1 = 0;
+  auto load_idx = [&](int64_t t, int& s, int& d, int& pc) {
+    int64_t p = t * kTile + c;
+    if (p > a.E - 1) p = a.E - 1;  // rows beyond the end repeat the last edge and are never stored
+    pc = static_cast<int>(p);
+    s = a.src[p];
+    d = a.dst[p];
+  };
+  if (tile < t_end) {
+    load_idx(tile, s0, d0, pc0);
+    if (tile + stride < t_end) load_idx(tile + stride, s1, d1, pc1);
+  }
+  for (; tile < t_end; tile += stride) {
     const int64_t p0 = tile * kTile;
     const int nvalid = (a.E - p0) < kTile ? static_cast<int>(a.E - p0) : kTile;  // >= 1: tile < ntiles
-    int64_t p = p0 + c;
-    if (p > a.E - 1) p = a.E - 1;
-    const int s = a.src[p], d = a.dst[p];
+    RowLanding<L> la, lb;
+    rows_issue<L>(la, a.e, pc0, lane);
+    rows_issue<L>(lb, a.Ps, s0, lane);
+    int s2 = 0, d2 = 0, pc2 = 0;
+    if (tile + 2 * stride < t_end) load_idx(tile + 2 * stride, s2, d2, pc2);
+    const int firstd = __builtin_amdgcn_readlane(d0, 0);
+    const int lastd = __builtin_amdgcn_readlane(d0, nvalid - 1);
+    const int rp_first = a.rowptr[firstd], rp_last = a.rowptr[lastd + 1];
 
     // The accumulator starts from the gathered first-layer terms (resp. the bias) moved into the scaled domain
     // (x 2^k, exact), the MFMAs add the scaled products, one multiply by 2^-k brings the sum back.
@@ -140,13 +216,16 @@ __global__ __launch_bounds__(kFastBlock) void edge_kernel_h(const EdgeArgs a, co
     float scale, inv;
     {
       Tile<L> ein;
-      tile_load_row<L>(ein, a.e, p, h);
-      tile_load_row<L>(acc, a.Ps, s, h);
-      tile_add_row<L>(acc, a.Pd, d, h);
+      rows_land<L, false>(ein, la, stage, lane);
+      rows_issue<L>(la, a.Pd, d0, lane);  // destination rows repeat inside a tile: L1 / L2 hits
+      rows_land<L, false>(acc, lb, stage, lane);
+      rows_land<L, true>(acc, la, stage, lane);
       tile_row_scale<L>(ein, scale, inv);
       tile_scale<L>(acc, scale * wscale0);
       tile_gemm_h<L>(acc, smem, ein, scale, lane);
     }
+    // residual rows: read again (this wave's own loads of a few microseconds ago, L2 / MALL resident) instead of
+    // being held in 64 registers across the remaining layers
     tile_scale<L>(acc, inv * wsinv0);
     tile_act_fast<L>(acc, a.act);
 #pragma unroll 1
@@ -160,67 +239,63 @@ __global__ __launch_bounds__(kFastBlock) void edge_kernel_h(const EdgeArgs a, co
       tile_act_fast<L>(nxt, a.act);
       acc = nxt;
     }
-    // residual: the old edge rows are read again (they were this wave's own loads a few microseconds ago and sit
-    // in L2) instead of being held in 64 registers across both GEMMs, which keeps the kernel at 2 waves per SIMD
-    if (a.residual == AMBER_MODE_INNER) tile_add_row<L>(acc, a.e, p, h);
+    if (a.residual == AMBER_MODE_INNER) {
+      RowLanding<L> lr;
+      rows_issue<L>(lr, a.e, pc0, lane);
+      rows_land<L, true>(acc, lr, stage, lane);
+    }
     if (a.layer_norm == AMBER_MODE_INNER) tile_layernorm<L>(acc, a.gamma, a.beta, a.eps, h);
 
-    // ---- epilogue: per-destination sums (half-wave h owns edges 16h .. 16h+15) and row stores, 32 features a pass ----
-    const int f = lane & 31;
-    int dcs[16];
+    // ---- epilogue, PF features a pass: per-destination sums in CSR order (lanes across features, all control
+    // flow wave-uniform), then whole-row-piece stores ----
+    const bool sb0 = p0 > static_cast<int64_t>(rp_first);
+    const bool ends_last = (p0 + nvalid) == static_cast<int64_t>(rp_last);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) dcs[i] = __shfl(d, 16 * h + i);
-    int nvh = nvalid - 16 * h;
-    nvh = nvh < 0 ? 0 : (nvh > 16 ? 16 : nvh);
-    const int64_t ph0 = p0 + 16 * h;
-    const int64_t rt = (p0 >> 4) + h;  // 16-edge reduction tile
-    bool sb0 = false, ends_last = false;
-    if (nvh > 0) {
-      const int lastd = __shfl(d, 16 * h + nvh - 1);
-      sb0 = ph0 > static_cast<int64_t>(a.rowptr[dcs[0]]);
-      ends_last = (ph0 + nvh) == static_cast<int64_t>(a.rowptr[lastd + 1]);
-    }
-#pragma unroll
-    for (int q = 0; q < NFB; ++q) {
+    for (int ps = 0; ps < G::NPASS; ++ps) {
       wave_sync();  // the previous pass's readers are done
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj)
-        *reinterpret_cast<f32x4*>(stage + c * 32 + (((2 * jj + h) ^ (c & 7)) << 2)) = tile_get_chunk<L>(acc, 4 * q + jj);
+      for (int jj = 0; jj < G::PF / 8; ++jj)
+        *reinterpret_cast<f32x4*>(stage + c * G::PF + (((2 * jj + h) ^ (c & (G::LPP - 1))) << 2)) =
+            tile_get_chunk<L>(acc, ps * (G::PF / 8) + jj);
       wave_sync();
-      if (nvh > 0) {
+      if (lane < G::PF) {
+        const int f = lane;
         float sum = 0.f;
-        int cur = dcs[0];
+        int cur = firstd;
         bool sb = sb0;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          if (i < nvh) {
-            const int dc = dcs[i];
+        for (int i = 0; i < kTile; ++i) {
+          if (i < nvalid) {
+            const int dc = __builtin_amdgcn_readlane(d0, i);
             if (dc != cur) {
-              float* dstp = sb ? a.head + rt * L : a.agg + static_cast<int64_t>(cur) * L;
-              dstp[32 * q + f] = sum;
+              float* dstp = sb ? a.head + tile * L : a.agg + static_cast<int64_t>(cur) * L;
+              dstp[ps * G::PF + f] = sum;
               cur = dc;
               sb = false;
               sum = 0.f;
             }
-            const int row = 16 * h + i;
-            sum += stage[row * 32 + ((((f >> 2) ^ (row & 7)) << 2) | (f & 3))];
+            sum += stage[i * G::PF + ((((f >> 2) ^ (i & (G::LPP - 1))) << 2) | (f & 3))];
           }
         }
-        float* dstp = (!sb && ends_last) ? a.agg + static_cast<int64_t>(cur) * L : (sb ? a.head + rt * L : a.tail + rt * L);
-        dstp[32 * q + f] = sum;
+        float* dstp = (!sb && ends_last) ? a.agg + static_cast<int64_t>(cur) * L : (sb ? a.head + tile * L : a.tail + tile * L);
+        dstp[ps * G::PF + f] = sum;
       }
       if (a.write_e || a.out_edge) {
+        const int slot = lane % G::LPP;
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-          const int r = it * 8 + (lane >> 3), slot = lane & 7;
-          const f32x4 v = *reinterpret_cast<const f32x4*>(stage + r * 32 + ((slot ^ (r & 7)) << 2));
+        for (int it = 0; it < G::NIT; ++it) {
+          const int r = it * G::RPI + lane / G::LPP;
+          const f32x4 v = *reinterpret_cast<const f32x4*>(stage + r * G::PF + ((slot ^ (r & (G::LPP - 1))) << 2));
           if (r < nvalid) {
-            if (a.write_e) *reinterpret_cast<f32x4*>(a.e + (p0 + r) * L + 32 * q + 4 * slot) = v;
-            if (a.out_edge) *reinterpret_cast<f32x4*>(a.out_edge + static_cast<int64_t>(a.perm[p0 + r]) * L + 32 * q + 4 * slot) = v;
+            if (a.write_e) *reinterpret_cast<f32x4*>(a.e + (p0 + r) * L + ps * G::PF + 4 * slot) = v;
+            if (a.out_edge)
+              *reinterpret_cast<f32x4*>(a.out_edge + static_cast<int64_t>(a.perm[p0 + r]) * L + ps * G::PF + 4 * slot) = v;
           }
         }
       }
     }
+    s0 = s1; d0 = d1; pc0 = pc1;
+    s1 = s2; d1 = d2; pc1 = pc2;
   }
 }
 
@@ -283,7 +358,9 @@ hipError_t launch_pack_h(int L, const float* W, int ld, int col0, float* out, hi
   }
 }
 
-size_t edge_fast_lds_bytes(int L, int nl) { return static_cast<size_t>(nl) * L * L * 4 + kFastWaves * kFastStageBytes; }
+size_t edge_fast_lds_bytes(int L, int nl) {
+  return static_cast<size_t>(nl) * L * L * 4 + static_cast<size_t>(kFastWaves) * kTile * 32 * 4;
+}
 
 bool edge_fast_supported(int L, int nl, int act, int residual, int layer_norm) {
   return (act == AMBER_ACT_RELU || act == AMBER_ACT_LEAKYRELU) && residual != AMBER_MODE_OUTER &&

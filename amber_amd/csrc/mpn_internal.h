@@ -42,7 +42,7 @@ struct EdgeArgs {
   float* agg;             // [N,L] sums of rows that lie inside one tile
   float* head;            // [T,L] partial sum of a tile's first row when that row began in an earlier tile
   float* tail;            // [T,L] partial sum of a tile's last row when it began here and continues
-  int32_t red_shift;      // log2 of the reduction tile the partial sums are indexed by (5: edge_kernel, 4: edge_kernel_h)
+  int32_t red_shift;      // log2 of the reduction tile the partial sums are indexed by (5 = 32 edges)
   int32_t write_e;        // store the updated e (CSR order)
   float* out_edge;        // [E,L] edge_index order, or nullptr
 };
