@@ -242,6 +242,9 @@ struct Timer {
 bool use_fast_edge(const AmberMpnDesc& d) {
   return d.precision == AMBER_PREC_F16X2 && edge_fast_supported(d.latent, d.mlp_layers, d.activation, d.residual, d.layer_norm);
 }
+bool use_fast_node(const AmberMpnDesc& d) {
+  return d.precision == AMBER_PREC_F16X2 && (d.activation == AMBER_ACT_RELU || d.activation == AMBER_ACT_LEAKYRELU);
+}
 int device_cus() {
   int dev = 0, cus = 0;
   if (hipGetDevice(&dev) != hipSuccess) return 256;
@@ -271,10 +274,13 @@ void fill_edge_step(EdgeArgs& a, const AmberMpnDesc& d, const Layout& lay, int s
   a.gamma = d.layer_norm != AMBER_MODE_NONE ? params + lay.eg[step] : nullptr;
   a.beta = d.layer_norm != AMBER_MODE_NONE ? params + lay.eb[step] : nullptr;
   a.eps = d.ln_eps;
+  const char* dbg = getenv("AMBER_MPN_DBG");
+  a.dbg = dbg ? atoi(dbg) : 0;
 }
 void fill_node_update(NodeArgs& a, const AmberMpnDesc& d, const Layout& lay, int step, const float* params, const float* packed) {
   const MlpLayout& m = lay.node[step];
   a.do_update = 1;
+  a.fast = use_fast_node(d) ? 1 : 0;
   a.w0x = packed + m.PW[0][0];
   a.w0a = packed + m.PW[0][1];
   a.b0 = params + m.B[0];
@@ -288,9 +294,11 @@ void fill_node_update(NodeArgs& a, const AmberMpnDesc& d, const Layout& lay, int
   a.beta = d.layer_norm != AMBER_MODE_NONE ? params + lay.nb[step] : nullptr;
   a.eps = d.ln_eps;
 }
-void fill_node_proj(NodeArgs& a, const Layout& lay, int step, const float* params, const float* packed, float* Ps, float* Pd) {
+void fill_node_proj(NodeArgs& a, const AmberMpnDesc& d, const Layout& lay, int step, const float* params, const float* packed,
+                    float* Ps, float* Pd) {
   const MlpLayout& m = lay.edge[step];
   a.do_proj = 1;
+  a.fast = use_fast_node(d) ? 1 : 0;
   a.w0s = packed + m.PW[0][0];
   a.w0d = packed + m.PW[0][1];
   a.b0e = params + m.B[0];
@@ -393,7 +401,7 @@ int forward_impl(const AmberMpnDesc* desc, const float* params, const float* pac
     NodeArgs a{};
     a.N = N;
     a.x_in = w.x;
-    fill_node_proj(a, lay, 0, params, packed, w.Ps, w.Pd);
+    fill_node_proj(a, d, lay, 0, params, packed, w.Ps, w.Pd);
     tm.begin(AMBER_KC_NODE);
     hipError_t e = launch_node(L, a, s);
     tm.end();
@@ -433,7 +441,7 @@ int forward_impl(const AmberMpnDesc* desc, const float* params, const float* pac
     fill_node_update(na, d, lay, step, params, packed);
     if (!last) {
       na.x_out = w.x;
-      fill_node_proj(na, lay, (it + 1) / d.num_step_repeats, params, packed, w.Ps, w.Pd);
+      fill_node_proj(na, d, lay, (it + 1) / d.num_step_repeats, params, packed, w.Ps, w.Pd);
     } else {
       na.x_out = out_node;
       if (want_head) fill_node_head(na, d, lay, params, packed, out_index, out_sizing);
@@ -473,20 +481,25 @@ int amber_mpn_pack_weights(const AmberMpnDesc* desc, const float* params, float*
   const Layout lay = build_layout(*desc);
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int L = desc->latent;
-  // `split_from`: first column block of layer 0 that the f16x2 edge kernel consumes (3 = none); its later
-  // layers are consumed by the same kernel.  Everything else stays in the exact fp32 operand format.
-  auto pack_mlp = [&](const MlpLayout& m, int blocks0, int split_from = 3) -> hipError_t {
+  // Per matrix the operand format follows its consumer: exact fp32 tiles, or hi/lo fp16 (f16x2) for the fast edge
+  // kernel (W0e and later edge layers) and the fast node kernel (node MLP, next-step W0s / W0d).  `h0[cb]` selects
+  // f16x2 for column block cb of layer 0, `share0` makes those blocks share one power-of-two scale (they feed one
+  // accumulator), `hrest` selects f16x2 for layers >= 1.
+  auto pack_mlp = [&](const MlpLayout& m, int blocks0, bool h00 = false, bool h01 = false, bool h02 = false, bool share0 = false,
+                      bool hrest = false) -> hipError_t {
+    const bool h0[3] = {h00, h01, h02};
     for (int l = 0; l < m.layers; ++l) {
       if (l == 0) {
         for (int cb = 0; cb < blocks0; ++cb)
           if (m.PW[0][cb] >= 0) {
-            hipError_t e = cb >= split_from ? launch_pack_h(L, params + m.W[0], m.in_cols, cb * L, packed + m.PW[0][cb], s)
-                                            : launch_pack(L, params + m.W[0], m.in_cols, cb * L, packed + m.PW[0][cb], s);
+            hipError_t e = h0[cb] ? launch_pack_h(L, params + m.W[0], m.in_cols, cb * L, share0 ? 0 : cb * L, share0 ? blocks0 * L : L,
+                                                  packed + m.PW[0][cb], s)
+                                  : launch_pack(L, params + m.W[0], m.in_cols, cb * L, packed + m.PW[0][cb], s);
             if (e != hipSuccess) return e;
           }
       } else if (m.PW[l][0] >= 0) {
-        hipError_t e = split_from < 3 ? launch_pack_h(L, params + m.W[l], L, 0, packed + m.PW[l][0], s)
-                                      : launch_pack(L, params + m.W[l], L, 0, packed + m.PW[l][0], s);
+        hipError_t e = hrest ? launch_pack_h(L, params + m.W[l], L, 0, 0, L, packed + m.PW[l][0], s)
+                             : launch_pack(L, params + m.W[l], L, 0, packed + m.PW[l][0], s);
         if (e != hipSuccess) return e;
       }
     }
@@ -495,8 +508,9 @@ int amber_mpn_pack_weights(const AmberMpnDesc* desc, const float* params, float*
   HIP_TRY(pack_mlp(lay.node_embed, 0), "pack node embedding");
   HIP_TRY(pack_mlp(lay.edge_embed, 0), "pack edge embedding");
   for (int st = 0; st < desc->num_steps; ++st) {
-    HIP_TRY(pack_mlp(lay.edge[st], 3, use_fast_edge(*desc) ? 2 : 3), "pack edge MLP");
-    HIP_TRY(pack_mlp(lay.node[st], 2), "pack node MLP");
+    const bool fe = use_fast_edge(*desc), fn = use_fast_node(*desc);
+    HIP_TRY(pack_mlp(lay.edge[st], 3, fn, fn, fe, false, fe), "pack edge MLP");
+    HIP_TRY(pack_mlp(lay.node[st], 2, fn, fn, false, true, fn), "pack node MLP");
   }
   if (desc->has_head) HIP_TRY(pack_mlp(lay.dec, 1), "pack decoder");
   return AMBER_OK;
@@ -596,7 +610,7 @@ int amber_mpn_block(const AmberMpnDesc* desc, const float* params, const float* 
   NodeArgs pa{};
   pa.N = num_nodes;
   pa.x_in = x_latent;
-  fill_node_proj(pa, lay, step, params, packed, w.Ps, w.Pd);
+  fill_node_proj(pa, *desc, lay, step, params, packed, w.Ps, w.Pd);
   HIP_TRY(launch_node(L, pa, s), "node projection kernel");
   EdgeArgs ea{};
   ea.E = num_edges;

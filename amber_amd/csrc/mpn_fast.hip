@@ -19,89 +19,8 @@
 
 namespace amber {
 
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-
 constexpr int kFastWaves = 8;  // two waves per SIMD (<= 256 registers each) overlap each other's memory and MFMA phases
 constexpr int kFastBlock = 64 * kFastWaves;
-
-DEVINL void wave_sync() {
-  // LDS instructions of one wave execute in order; this only stops the compiler from moving LDS accesses of
-  // different lanes' data across the hand-over point.
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-constexpr int kMinScaleExp = 127 - 24;
-
-// power-of-two scale that brings max|row| into [2^14, 2^15), and its inverse
-template <int L>
-DEVINL void tile_row_scale(const Tile<L>& t, float& scale, float& inv) {
-  float m0 = 0.f, m1 = 0.f;
-#pragma unroll
-  for (int fb = 0; fb < L / 32; ++fb)
-#pragma unroll
-    for (int i = 0; i < 16; i += 2) {
-      m0 = fmaxf(m0, fabsf(t.a[fb][i]));
-      m1 = fmaxf(m1, fabsf(t.a[fb][i + 1]));
-    }
-  float m = fmaxf(m0, m1);
-  m = fmaxf(m, __shfl_xor(m, 32));
-  int ex = static_cast<int>((__float_as_uint(m) >> 23) & 0xffu);
-  ex = ex < kMinScaleExp ? kMinScaleExp : ex;  // rows below 2^-24 keep a bounded scale (no overflow of scaled biases)
-  scale = __uint_as_float(static_cast<unsigned>(268 - ex) << 23);
-  inv = __uint_as_float(static_cast<unsigned>(ex - 14) << 23);
-}
-
-// acc += (W * scale_w) * (in * scale), W pre-split and pre-tiled in LDS: [k-step s][fb][hi|lo][lane] x 16 B
-template <int L>
-DEVINL void tile_gemm_h(Tile<L>& acc, const unsigned char* wl, const Tile<L>& in, float scale, int lane) {
-  constexpr int NFB = L / 32, NS = L / 16;
-  const half8* w = reinterpret_cast<const half8*>(wl) + lane;
-#pragma unroll
-  for (int s = 0; s < NS; ++s) {
-    half8 bh, bl;
-#pragma unroll
-    for (int jj = 0; jj < 8; ++jj) {
-      const int j = 2 * s + (jj >> 2), t = jj & 3;
-      const float xs = in.a[j >> 2][(j & 3) * 4 + t] * scale;
-      const _Float16 hi = static_cast<_Float16>(xs);
-      bh[jj] = hi;
-      bl[jj] = static_cast<_Float16>(xs - static_cast<float>(hi));
-    }
-    half8 ah[NFB], al[NFB];
-#pragma unroll
-    for (int fb = 0; fb < NFB; ++fb) {
-      ah[fb] = w[((s * NFB + fb) * 2 + 0) * 64];
-      al[fb] = w[((s * NFB + fb) * 2 + 1) * 64];
-    }
-#pragma unroll
-    for (int fb = 0; fb < NFB; ++fb) acc.a[fb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[fb], bh, acc.a[fb], 0, 0, 0);
-#pragma unroll
-    for (int fb = 0; fb < NFB; ++fb) acc.a[fb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[fb], bl, acc.a[fb], 0, 0, 0);
-#pragma unroll
-    for (int fb = 0; fb < NFB; ++fb) acc.a[fb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[fb], bh, acc.a[fb], 0, 0, 0);
-  }
-}
-
-// t *= factor (a power of two: exact)
-template <int L>
-DEVINL void tile_scale(Tile<L>& t, float factor) {
-#pragma unroll
-  for (int fb = 0; fb < L / 32; ++fb) t.a[fb] = t.a[fb] * factor;
-}
-
-template <int L>
-DEVINL void tile_act_fast(Tile<L>& t, int act) {
-  const float slope = act == AMBER_ACT_LEAKYRELU ? 0.01f : 0.f;
-#pragma unroll
-  for (int fb = 0; fb < L / 32; ++fb)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const float v = t.a[fb][i];
-      t.a[fb][i] = fmaxf(v, slope * v);  // slope in [0, 1): max picks v for v > 0 and slope * v otherwise
-    }
-}
 
 // Coalesced row traffic.  A lane-per-row 16-byte load touches 32 different rows per wave instruction; instead every
 // wave instruction reads whole row pieces of PF features (PF * 4 bytes, whole 128-byte lines) into a register
@@ -203,7 +122,7 @@ __global__ __launch_bounds__(kFastBlock) void edge_kernel_h(const EdgeArgs a, co
     const int nvalid = (a.E - p0) < kTile ? static_cast<int>(a.E - p0) : kTile;  // >= 1: tile < ntiles
     RowLanding<L> la, lb;
     rows_issue<L>(la, a.e, pc0, lane);
-    rows_issue<L>(lb, a.Ps, s0, lane);
+    rows_issue<L>(lb, (a.dbg & 32) ? a.e : a.Ps, (a.dbg & 32) ? pc0 : s0, lane);
     int s2 = 0, d2 = 0, pc2 = 0;
     if (tile + 2 * stride < t_end) load_idx(tile + 2 * stride, s2, d2, pc2);
     const int firstd = __builtin_amdgcn_readlane(d0, 0);
@@ -217,12 +136,12 @@ __global__ __launch_bounds__(kFastBlock) void edge_kernel_h(const EdgeArgs a, co
     {
       Tile<L> ein;
       rows_land<L, false>(ein, la, stage, lane);
-      rows_issue<L>(la, a.Pd, d0, lane);  // destination rows repeat inside a tile: L1 / L2 hits
+      if (!(a.dbg & 2)) rows_issue<L>(la, a.Pd, d0, lane);  // destination rows repeat inside a tile: L1 / L2 hits
       rows_land<L, false>(acc, lb, stage, lane);
-      rows_land<L, true>(acc, la, stage, lane);
+      if (!(a.dbg & 2)) rows_land<L, true>(acc, la, stage, lane);
       tile_row_scale<L>(ein, scale, inv);
       tile_scale<L>(acc, scale * wscale0);
-      tile_gemm_h<L>(acc, smem, ein, scale, lane);
+      if (!(a.dbg & 8)) tile_gemm_h<L>(acc, smem, ein, scale, lane);
     }
     // residual rows: read again (this wave's own loads of a few microseconds ago, L2 / MALL resident) instead of
     // being held in 64 registers across the remaining layers
@@ -234,12 +153,12 @@ __global__ __launch_bounds__(kFastBlock) void edge_kernel_h(const EdgeArgs a, co
       tile_row_scale<L>(acc, scale, inv);
       tile_load_vec<L>(nxt, a.layers[l].b, h);
       tile_scale<L>(nxt, scale * a.layers[l].w[L * L + 1]);
-      tile_gemm_h<L>(nxt, smem + l * MAT_BYTES, acc, scale, lane);
+      if (!(a.dbg & 8)) tile_gemm_h<L>(nxt, smem + l * MAT_BYTES, acc, scale, lane);
       tile_scale<L>(nxt, inv * a.layers[l].w[L * L]);
       tile_act_fast<L>(nxt, a.act);
       acc = nxt;
     }
-    if (a.residual == AMBER_MODE_INNER) {
+    if (a.residual == AMBER_MODE_INNER && !(a.dbg & 1)) {
       RowLanding<L> lr;
       rows_issue<L>(lr, a.e, pc0, lane);
       rows_land<L, true>(acc, lr, stage, lane);
@@ -258,7 +177,7 @@ __global__ __launch_bounds__(kFastBlock) void edge_kernel_h(const EdgeArgs a, co
         *reinterpret_cast<f32x4*>(stage + c * G::PF + (((2 * jj + h) ^ (c & (G::LPP - 1))) << 2)) =
             tile_get_chunk<L>(acc, ps * (G::PF / 8) + jj);
       wave_sync();
-      if (lane < G::PF) {
+      if (lane < G::PF && !(a.dbg & 4)) {
         const int f = lane;
         float sum = 0.f;
         int cur = firstd;
@@ -287,7 +206,7 @@ __global__ __launch_bounds__(kFastBlock) void edge_kernel_h(const EdgeArgs a, co
           const int r = it * G::RPI + lane / G::LPP;
           const f32x4 v = *reinterpret_cast<const f32x4*>(stage + r * G::PF + ((slot ^ (r & (G::LPP - 1))) << 2));
           if (r < nvalid) {
-            if (a.write_e) *reinterpret_cast<f32x4*>(a.e + (p0 + r) * L + ps * G::PF + 4 * slot) = v;
+            if (a.write_e && !(a.dbg & 16)) *reinterpret_cast<f32x4*>(a.e + (p0 + r) * L + ps * G::PF + 4 * slot) = v;
             if (a.out_edge)
               *reinterpret_cast<f32x4*>(a.out_edge + static_cast<int64_t>(a.perm[p0 + r]) * L + ps * G::PF + 4 * slot) = v;
           }
@@ -302,10 +221,10 @@ __global__ __launch_bounds__(kFastBlock) void edge_kernel_h(const EdgeArgs a, co
 // ---------------------------------------------------------------------------------------------------
 // weight packing: absmax -> power-of-two scale -> hi/lo fp16 in MFMA operand order (+ header)
 // ---------------------------------------------------------------------------------------------------
-__global__ void absmax_kernel(const float* __restrict__ W, int ld, int col0, int L, unsigned* __restrict__ out_bits) {
+__global__ void absmax_kernel(const float* __restrict__ W, int ld, int col0, int ncols, int L, unsigned* __restrict__ out_bits) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= L * L) return;
-  const float v = fabsf(W[static_cast<int64_t>(i / L) * ld + col0 + (i % L)]);
+  if (i >= L * ncols) return;
+  const float v = fabsf(W[static_cast<int64_t>(i / ncols) * ld + col0 + (i % ncols)]);
   atomicMax(out_bits, __float_as_uint(v));  // non-negative floats order like their bit patterns; integer atomic
 }
 
@@ -340,20 +259,20 @@ __global__ void pack_h_kernel(const float* __restrict__ W, int ld, int col0, flo
 }
 
 template <int L>
-static hipError_t launch_pack_h_t(const float* W, int ld, int col0, float* out, hipStream_t s) {
+static hipError_t launch_pack_h_t(const float* W, int ld, int col0, int scale_col0, int scale_cols, float* out, hipStream_t s) {
   unsigned* bits = reinterpret_cast<unsigned*>(out + L * L + 4);  // scratch word inside the header
   hipError_t e = hipMemsetAsync(bits, 0, sizeof(unsigned), s);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(absmax_kernel, dim3((L * L + 255) / 256), dim3(256), 0, s, W, ld, col0, L, bits);
+  hipLaunchKernelGGL(absmax_kernel, dim3((L * scale_cols + 255) / 256), dim3(256), 0, s, W, ld, scale_col0, scale_cols, L, bits);
   hipLaunchKernelGGL(pack_h_kernel<L>, dim3((L / 16 * (L / 32) * 64 + 255) / 256), dim3(256), 0, s, W, ld, col0, out, bits);
   return hipGetLastError();
 }
 
-hipError_t launch_pack_h(int L, const float* W, int ld, int col0, float* out, hipStream_t s) {
+hipError_t launch_pack_h(int L, const float* W, int ld, int col0, int scale_col0, int scale_cols, float* out, hipStream_t s) {
   switch (L) {
-    case 32: return launch_pack_h_t<32>(W, ld, col0, out, s);
-    case 64: return launch_pack_h_t<64>(W, ld, col0, out, s);
-    case 128: return launch_pack_h_t<128>(W, ld, col0, out, s);
+    case 32: return launch_pack_h_t<32>(W, ld, col0, scale_col0, scale_cols, out, s);
+    case 64: return launch_pack_h_t<64>(W, ld, col0, scale_col0, scale_cols, out, s);
+    case 128: return launch_pack_h_t<128>(W, ld, col0, scale_col0, scale_cols, out, s);
     default: return hipErrorInvalidValue;
   }
 }

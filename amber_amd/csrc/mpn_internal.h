@@ -45,6 +45,7 @@ struct EdgeArgs {
   int32_t red_shift;      // log2 of the reduction tile the partial sums are indexed by (5 = 32 edges)
   int32_t write_e;        // store the updated e (CSR order)
   float* out_edge;        // [E,L] edge_index order, or nullptr
+  int32_t dbg;            // experiment switches (AMBER_MPN_DBG), 0 in production
 };
 
 // Arguments of the fused node kernel (K6 finish, K7, K8, next step's first-layer projections, K9, K10).
@@ -59,6 +60,7 @@ struct NodeArgs {
   const float* head;
   const float* tail;
   int32_t red_shift;      // log2 of the reduction tile of head / tail (must match the edge kernel that wrote them)
+  int32_t fast;           // update / projection weights are in the split-precision (f16x2) operand format
   const float* w0x;       // packed W0[:, 0:L]
   const float* w0a;       // packed W0[:, L:2L]
   const float* b0;
@@ -100,7 +102,9 @@ hipError_t launch_embed(int L, const float* in, int64_t rows, int F, const float
 hipError_t launch_pack(int L, const float* W, int ld, int col0, float* out, hipStream_t s);
 // split-precision (f16x2) path, mpn_fast.hip.  A packed matrix is L*L floats of body + kPackedHeader floats.
 constexpr int kPackedHeader = 8;
-hipError_t launch_pack_h(int L, const float* W, int ld, int col0, float* out, hipStream_t s);
+// scale_col0 / scale_cols: the column range of W whose max |w| fixes the power-of-two scale (matrices that feed one
+// accumulator, such as the two halves of the node MLP's first layer, must share it)
+hipError_t launch_pack_h(int L, const float* W, int ld, int col0, int scale_col0, int scale_cols, float* out, hipStream_t s);
 hipError_t launch_edge_h(int L, const EdgeArgs& a, int num_cus, hipStream_t s);
 bool edge_fast_supported(int L, int nl, int act, int residual, int layer_norm);
 hipError_t launch_segment_mean(const float* vals, const int32_t* rowptr, int64_t N, int L, float* out, hipStream_t s);
