@@ -240,7 +240,7 @@ struct Timer {
 };
 
 bool use_fast_edge(const AmberMpnDesc& d) {
-  return d.precision == AMBER_PREC_F16X2 && edge_fast_supported(d.latent, d.mlp_layers, d.activation, d.residual, d.layer_norm);
+  return d.precision == AMBER_PREC_F16X2 && edge_f2_supported(d.latent, d.mlp_layers, d.activation, d.residual, d.layer_norm);
 }
 bool use_fast_node(const AmberMpnDesc& d) {
   return d.precision == AMBER_PREC_F16X2 && (d.activation == AMBER_ACT_RELU || d.activation == AMBER_ACT_LEAKYRELU);
@@ -254,7 +254,7 @@ int device_cus() {
 hipError_t run_edge(const AmberMpnDesc& d, EdgeArgs& ea, hipStream_t s) {
   if (use_fast_edge(d)) {
     ea.red_shift = 5;
-    return launch_edge_h(d.latent, ea, device_cus(), s);
+    return launch_edge_f2(d.latent, ea, device_cus(), s);
   }
   ea.red_shift = 5;
   return launch_edge(d.latent, ea, s);
@@ -481,25 +481,30 @@ int amber_mpn_pack_weights(const AmberMpnDesc* desc, const float* params, float*
   const Layout lay = build_layout(*desc);
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int L = desc->latent;
-  // Per matrix the operand format follows its consumer: exact fp32 tiles, or hi/lo fp16 (f16x2) for the fast edge
-  // kernel (W0e and later edge layers) and the fast node kernel (node MLP, next-step W0s / W0d).  `h0[cb]` selects
-  // f16x2 for column block cb of layer 0, `share0` makes those blocks share one power-of-two scale (they feed one
-  // accumulator), `hrest` selects f16x2 for layers >= 1.
-  auto pack_mlp = [&](const MlpLayout& m, int blocks0, bool h00 = false, bool h01 = false, bool h02 = false, bool share0 = false,
-                      bool hrest = false) -> hipError_t {
-    const bool h0[3] = {h00, h01, h02};
+  // Per matrix the operand format follows its consumer: FMT_F32 = exact fp32 tiles; FMT_H = hi/lo fp16 (f16x2) as
+  // the A operand of the row-per-lane chain (fast node kernel: node MLP, next-step W0s / W0d); FMT_F2 = hi/lo fp16 as
+  // the B operand of the feature-per-lane chain (edge kernel: W0e and later edge layers).  `f0[cb]` is the format
+  // of column block cb of layer 0, `share0` makes its FMT_H blocks share one power-of-two scale (they feed one
+  // accumulator), `frest` is the format of layers >= 1.
+  enum { FMT_F32 = 0, FMT_H = 1, FMT_F2 = 2 };
+  auto pack_one = [&](int fmt, const float* W, int ld, int col0, int scol0, int scols, float* out) -> hipError_t {
+    if (fmt == FMT_H) return launch_pack_h(L, W, ld, col0, scol0, scols, out, s);
+    if (fmt == FMT_F2) return launch_pack_f2(L, W, ld, col0, scol0, scols, out, s);
+    return launch_pack(L, W, ld, col0, out, s);
+  };
+  auto pack_mlp = [&](const MlpLayout& m, int blocks0, int f00 = FMT_F32, int f01 = FMT_F32, int f02 = FMT_F32, bool share0 = false,
+                      int frest = FMT_F32) -> hipError_t {
+    const int f0[3] = {f00, f01, f02};
     for (int l = 0; l < m.layers; ++l) {
       if (l == 0) {
         for (int cb = 0; cb < blocks0; ++cb)
           if (m.PW[0][cb] >= 0) {
-            hipError_t e = h0[cb] ? launch_pack_h(L, params + m.W[0], m.in_cols, cb * L, share0 ? 0 : cb * L, share0 ? blocks0 * L : L,
-                                                  packed + m.PW[0][cb], s)
-                                  : launch_pack(L, params + m.W[0], m.in_cols, cb * L, packed + m.PW[0][cb], s);
+            hipError_t e = pack_one(f0[cb], params + m.W[0], m.in_cols, cb * L, share0 ? 0 : cb * L, share0 ? blocks0 * L : L,
+                                    packed + m.PW[0][cb]);
             if (e != hipSuccess) return e;
           }
       } else if (m.PW[l][0] >= 0) {
-        hipError_t e = hrest ? launch_pack_h(L, params + m.W[l], L, 0, 0, L, packed + m.PW[l][0], s)
-                             : launch_pack(L, params + m.W[l], L, 0, packed + m.PW[l][0], s);
+        hipError_t e = pack_one(frest, params + m.W[l], L, 0, 0, L, packed + m.PW[l][0]);
         if (e != hipSuccess) return e;
       }
     }
@@ -508,9 +513,9 @@ int amber_mpn_pack_weights(const AmberMpnDesc* desc, const float* params, float*
   HIP_TRY(pack_mlp(lay.node_embed, 0), "pack node embedding");
   HIP_TRY(pack_mlp(lay.edge_embed, 0), "pack edge embedding");
   for (int st = 0; st < desc->num_steps; ++st) {
-    const bool fe = use_fast_edge(*desc), fn = use_fast_node(*desc);
+    const int fe = use_fast_edge(*desc) ? FMT_F2 : FMT_F32, fn = use_fast_node(*desc) ? FMT_H : FMT_F32;
     HIP_TRY(pack_mlp(lay.edge[st], 3, fn, fn, fe, false, fe), "pack edge MLP");
-    HIP_TRY(pack_mlp(lay.node[st], 2, fn, fn, false, true, fn), "pack node MLP");
+    HIP_TRY(pack_mlp(lay.node[st], 2, fn, fn, FMT_F32, true, fn), "pack node MLP");
   }
   if (desc->has_head) HIP_TRY(pack_mlp(lay.dec, 1), "pack decoder");
   return AMBER_OK;

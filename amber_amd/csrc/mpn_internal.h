@@ -105,8 +105,10 @@ constexpr int kPackedHeader = 8;
 // scale_col0 / scale_cols: the column range of W whose max |w| fixes the power-of-two scale (matrices that feed one
 // accumulator, such as the two halves of the node MLP's first layer, must share it)
 hipError_t launch_pack_h(int L, const float* W, int ld, int col0, int scale_col0, int scale_cols, float* out, hipStream_t s);
-hipError_t launch_edge_h(int L, const EdgeArgs& a, int num_cus, hipStream_t s);
-bool edge_fast_supported(int L, int nl, int act, int residual, int layer_norm);
+// feature-per-lane split-precision edge kernel, mpn_f2.hip (weights as B operand: launch_pack_f2)
+hipError_t launch_pack_f2(int L, const float* W, int ld, int col0, int scale_col0, int scale_cols, float* out, hipStream_t s);
+hipError_t launch_edge_f2(int L, const EdgeArgs& a, int num_cus, hipStream_t s);
+bool edge_f2_supported(int L, int nl, int act, int residual, int layer_norm);
 hipError_t launch_segment_mean(const float* vals, const int32_t* rowptr, int64_t N, int L, float* out, hipStream_t s);
 hipError_t launch_permute_rows(const float* in, const int32_t* perm, int64_t rows, int width, int gather, float* out,
                                hipStream_t s);
