@@ -28,6 +28,14 @@
 // MessagePassingBlock.forward (src/mpn/message_passing_block.py:117-121), scatter_mean (message_passing_modules.py:68).
 #include "mpn_tile.h"
 
+// experiment switches for tools/exp_dbg.py (timing only, results are wrong with a switch on): build with
+// make EXTRA=-DAMBER_DBG_SWITCHES; compiled out otherwise
+#ifdef AMBER_DBG_SWITCHES
+#define DBG(bit) (a.dbg & (bit))
+#else
+#define DBG(bit) 0
+#endif
+
 namespace amber {
 
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
@@ -185,13 +193,18 @@ __global__ __launch_bounds__(kF2Block) void edge_kernel_f2(const EdgeArgs a, con
   for (; tile < t_end; tile += stride) {
     const int64_t p0 = tile * kTile;
     const int nvalid = (a.E - p0) < kTile ? static_cast<int>(a.E - p0) : kTile;  // >= 1: tile < ntiles
+    float* const et = a.e + p0 * L;     // this tile's rows of e (wave-uniform base, 32-bit lane offsets)
+    const int rlim = nvalid - 1;
+    // Lane offsets of the direct row accesses are recomputed per tile from these opaque copies: hoisted out of the tile
+    // loop they would occupy dozens of registers for its whole length.
+    int hq = 4 * h * L + n, nq = n;
+    asm volatile("" : "+v"(hq), "+v"(nq));
     // ---- streamed e rows (whole row pieces) ----
     ELanding<L> la;
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
-      int64_t row = p0 + it * 8 + (lane >> 3);
-      if (row > a.E - 1) row = a.E - 1;
-      const f32x4* p = reinterpret_cast<const f32x4*>(a.e + row * L) + (lane & 7);
+      const int r = it * 8 + (lane >> 3);
+      const f32x4* p = reinterpret_cast<const f32x4*>(et + static_cast<unsigned>((r < rlim ? r : rlim) * L)) + (lane & 7);
 #pragma unroll
       for (int ps = 0; ps < NFB; ++ps) la.v[ps][it] = p[ps * 8];
     }
@@ -201,7 +214,7 @@ __global__ __launch_bounds__(kF2Block) void edge_kernel_f2(const EdgeArgs a, con
     for (int i = 0; i < 16; ++i) {
       const int r = 8 * (i >> 2) + (i & 3) + 4 * h;
       const int si = __shfl(s0, r);
-      const float* ps = a.Ps + static_cast<int64_t>(si) * L + n;
+      const float* ps = a.Ps + static_cast<int64_t>(DBG(32) ? 0 : si) * L + n;
 #pragma unroll
       for (int fb = 0; fb < NFB; ++fb) acc.a[fb][i] = ps[32 * fb];
     }
@@ -243,7 +256,7 @@ __global__ __launch_bounds__(kF2Block) void edge_kernel_f2(const EdgeArgs a, con
       for (int sp = 0; sp < 2; ++sp) {
         const half8 ah = *reinterpret_cast<const half8*>(win + er_off[sp]);
         const half8 al = *reinterpret_cast<const half8*>(win + kLoPlane + er_off[sp]);
-        kstep<L>(acc, ah, al, smem, 2 * ps + sp, lane);
+        if (!DBG(8)) kstep<L>(acc, ah, al, smem, 2 * ps + sp, lane);
       }
     }
     // destination terms (rows repeat inside a tile: L1 / L2 hits) join after the contraction, when the landing
@@ -253,7 +266,7 @@ __global__ __launch_bounds__(kF2Block) void edge_kernel_f2(const EdgeArgs a, con
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int di = __shfl(d0, 8 * (i >> 2) + (i & 3) + 4 * h);
-        const float* pd = a.Pd + static_cast<int64_t>(di) * L + n;
+        const float* pd = a.Pd + static_cast<int64_t>(DBG(2) ? 0 : di) * L + n;
 #pragma unroll
         for (int fb = 0; fb < NFB; ++fb) acc.a[fb][i] = fmaf(acc.a[fb][i], us, pd[32 * fb]);
       }
@@ -302,7 +315,7 @@ __global__ __launch_bounds__(kF2Block) void edge_kernel_f2(const EdgeArgs a, con
             al[t] = b0[t];
             al[4 + t] = b1[t];
           }
-          kstep<L>(nxt, ah, al, smem + l * MAT_BYTES, 2 * fb + sp, lane);
+          if (!DBG(8)) kstep<L>(nxt, ah, al, smem + l * MAT_BYTES, 2 * fb + sp, lane);
         }
       }
       tile_scale<L>(nxt, inv * wg[L * L]);
@@ -310,18 +323,18 @@ __global__ __launch_bounds__(kF2Block) void edge_kernel_f2(const EdgeArgs a, con
       acc = nxt;
     }
     // ---- residual: the rows of e again (this wave's own loads of a moment ago), now feature per lane ----
-    if (a.residual == AMBER_MODE_INNER) {
+    if (a.residual == AMBER_MODE_INNER && !DBG(1)) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        int64_t row = p0 + 8 * (i >> 2) + (i & 3) + 4 * h;
-        if (row > a.E - 1) row = a.E - 1;
-        const float* pe = a.e + row * L + n;
+        // rows beyond the end repeat the last edge
+        const unsigned off = nvalid == kTile ? static_cast<unsigned>(hq + (8 * (i >> 2) + (i & 3)) * L)
+                                             : static_cast<unsigned>(min(8 * (i >> 2) + (i & 3) + 4 * h, rlim) * L + n);
 #pragma unroll
-        for (int fb = 0; fb < NFB; ++fb) acc.a[fb][i] += pe[32 * fb];
+        for (int fb = 0; fb < NFB; ++fb) acc.a[fb][i] += et[off + 32 * fb];
       }
     }
     // ---- LayerNorm over the features of every edge: across the lanes of a half, one register per edge ----
-    if (a.layer_norm == AMBER_MODE_INNER) {
+    if (a.layer_norm == AMBER_MODE_INNER && !DBG(64)) {
       float g[NFB], bt[NFB];
 #pragma unroll
       for (int fb = 0; fb < NFB; ++fb) {
@@ -341,7 +354,7 @@ __global__ __launch_bounds__(kF2Block) void edge_kernel_f2(const EdgeArgs a, con
           acc.a[fb][i] = dlt;
           q += dlt * dlt;
         }
-        const float rstd = 1.0f / sqrtf(half_sum(q) * (1.0f / L) + a.eps);
+        const float rstd = __builtin_amdgcn_rsqf(half_sum(q) * (1.0f / L) + a.eps);  // v_rsq_f32: 1 ulp
 #pragma unroll
         for (int fb = 0; fb < NFB; ++fb) acc.a[fb][i] = acc.a[fb][i] * rstd * g[fb] + bt[fb];
       }
@@ -354,17 +367,31 @@ __global__ __launch_bounds__(kF2Block) void edge_kernel_f2(const EdgeArgs a, con
         if (p > a.E - 1) p = a.E - 1;
         pm = a.perm[p];
       }
+      if (a.write_e && !DBG(16)) {
+        if (nvalid == kTile) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int r = 8 * (i >> 2) + (i & 3) + 4 * h;
-        const int orow = a.out_edge ? __shfl(pm, r) : 0;
-        if (r < nvalid) {
-          if (a.write_e) {
-            float* pe = a.e + (p0 + r) * L + n;
+          for (int i = 0; i < 16; ++i) {
+            const unsigned off = static_cast<unsigned>(hq + (8 * (i >> 2) + (i & 3)) * L);
 #pragma unroll
-            for (int fb = 0; fb < NFB; ++fb) pe[32 * fb] = acc.a[fb][i];
+            for (int fb = 0; fb < NFB; ++fb) et[off + 32 * fb] = acc.a[fb][i];
           }
-          if (a.out_edge) {
+        } else {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int r = 8 * (i >> 2) + (i & 3) + 4 * h;
+            if (r < nvalid) {
+#pragma unroll
+              for (int fb = 0; fb < NFB; ++fb) et[static_cast<unsigned>(hq + (8 * (i >> 2) + (i & 3)) * L) + 32 * fb] = acc.a[fb][i];
+            }
+          }
+        }
+      }
+      if (a.out_edge) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int r = 8 * (i >> 2) + (i & 3) + 4 * h;
+          const int orow = __shfl(pm, r);
+          if (r < nvalid) {
             float* po = a.out_edge + static_cast<int64_t>(orow) * L + n;
 #pragma unroll
             for (int fb = 0; fb < NFB; ++fb) po[32 * fb] = acc.a[fb][i];
@@ -384,6 +411,7 @@ __global__ __launch_bounds__(kF2Block) void edge_kernel_f2(const EdgeArgs a, con
           }
       }
       const bool ends_last = (p0 + nvalid) == static_cast<int64_t>(rp_last);
+      if (!DBG(4)) {
       bool sb = p0 > static_cast<int64_t>(rp_first);
       float sum[NFB];
 #pragma unroll
@@ -391,8 +419,10 @@ __global__ __launch_bounds__(kF2Block) void edge_kernel_f2(const EdgeArgs a, con
       auto flush = [&](float* dstp) {
 #pragma unroll
         for (int fb = 0; fb < NFB; ++fb) {
-          const float tot = sum[fb] + __shfl_xor(sum[fb], 32);
-          if (h == 0) dstp[32 * fb + n] = tot;
+          // both halves' partial sums: swap the upper half of one copy with the lower half of the other
+          const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(sum[fb]), __float_as_uint(sum[fb]), false, false);
+          const float tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+          if (h == 0) dstp[static_cast<unsigned>(nq) + 32 * fb] = tot;
           sum[fb] = 0.f;
         }
       };
@@ -408,6 +438,7 @@ __global__ __launch_bounds__(kF2Block) void edge_kernel_f2(const EdgeArgs a, con
         for (int fb = 0; fb < NFB; ++fb) sum[fb] = fmaf(acc.a[fb][i], mk, sum[fb]);
       }
       flush((!sb && ends_last) ? a.agg + static_cast<int64_t>(lastd) * L : (sb ? a.head + tile * L : a.tail + tile * L));
+      }
     }
     s0 = s1; d0 = d1;
     s1 = s2; d1 = d2;
