@@ -243,7 +243,7 @@ bool use_fast_edge(const AmberMpnDesc& d) {
   return d.precision == AMBER_PREC_F16X2 && edge_f2_supported(d.latent, d.mlp_layers, d.activation, d.residual, d.layer_norm);
 }
 bool use_fast_node(const AmberMpnDesc& d) {
-  return d.precision == AMBER_PREC_F16X2 && (d.activation == AMBER_ACT_RELU || d.activation == AMBER_ACT_LEAKYRELU);
+  return d.precision == AMBER_PREC_F16X2 && node_f2_supported(d.latent, d.activation, d.residual, d.layer_norm);
 }
 int device_cus() {
   int dev = 0, cus = 0;
@@ -258,6 +258,25 @@ hipError_t run_edge(const AmberMpnDesc& d, EdgeArgs& ea, hipStream_t s) {
   }
   ea.red_shift = 5;
   return launch_edge(d.latent, ea, s);
+}
+
+// Node launch: the split-precision kernel does the update and the projections; a decoder / readout that rides on the
+// same launch (the exact dense chain) follows as a launch of its own on the updated rows.
+hipError_t run_node(const AmberMpnDesc& d, const NodeArgs& na, hipStream_t s) {
+  if (!na.fast) return launch_node(d.latent, na, s);
+  NodeArgs u = na;
+  u.n_dense = 0;
+  u.do_readout = 0;
+  u.dense_out = nullptr;
+  hipError_t e = launch_node_f2(d.latent, u, device_cus(), s);
+  if (e != hipSuccess || (na.n_dense == 0 && !na.do_readout)) return e;
+  NodeArgs hd = na;
+  hd.fast = 0;
+  hd.do_update = 0;
+  hd.do_proj = 0;
+  hd.x_in = na.do_update ? na.x_out : na.x_in;
+  hd.x_out = nullptr;
+  return launch_node(d.latent, hd, s);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -403,7 +422,7 @@ int forward_impl(const AmberMpnDesc* desc, const float* params, const float* pac
     a.x_in = w.x;
     fill_node_proj(a, d, lay, 0, params, packed, w.Ps, w.Pd);
     tm.begin(AMBER_KC_NODE);
-    hipError_t e = launch_node(L, a, s);
+    hipError_t e = run_node(d, a, s);
     tm.end();
     HIP_TRY(e, "node projection kernel");
   }
@@ -444,10 +463,13 @@ int forward_impl(const AmberMpnDesc* desc, const float* params, const float* pac
       fill_node_proj(na, d, lay, (it + 1) / d.num_step_repeats, params, packed, w.Ps, w.Pd);
     } else {
       na.x_out = out_node;
-      if (want_head) fill_node_head(na, d, lay, params, packed, out_index, out_sizing);
+      if (want_head) {
+        fill_node_head(na, d, lay, params, packed, out_index, out_sizing);
+        if (na.fast && !out_node) na.x_out = w.x;  // the head runs as a launch of its own on the updated rows
+      }
     }
     tm.begin(AMBER_KC_NODE);
-    e = launch_node(L, na, s);
+    e = run_node(d, na, s);
     tm.end();
     HIP_TRY(e, "node kernel");
   }
@@ -513,7 +535,7 @@ int amber_mpn_pack_weights(const AmberMpnDesc* desc, const float* params, float*
   HIP_TRY(pack_mlp(lay.node_embed, 0), "pack node embedding");
   HIP_TRY(pack_mlp(lay.edge_embed, 0), "pack edge embedding");
   for (int st = 0; st < desc->num_steps; ++st) {
-    const int fe = use_fast_edge(*desc) ? FMT_F2 : FMT_F32, fn = use_fast_node(*desc) ? FMT_H : FMT_F32;
+    const int fe = use_fast_edge(*desc) ? FMT_F2 : FMT_F32, fn = use_fast_node(*desc) ? FMT_F2 : FMT_F32;
     HIP_TRY(pack_mlp(lay.edge[st], 3, fn, fn, fe, false, fe), "pack edge MLP");
     HIP_TRY(pack_mlp(lay.node[st], 2, fn, fn, FMT_F32, true, fn), "pack node MLP");
   }
@@ -616,7 +638,7 @@ int amber_mpn_block(const AmberMpnDesc* desc, const float* params, const float* 
   pa.N = num_nodes;
   pa.x_in = x_latent;
   fill_node_proj(pa, *desc, lay, step, params, packed, w.Ps, w.Pd);
-  HIP_TRY(launch_node(L, pa, s), "node projection kernel");
+  HIP_TRY(run_node(*desc, pa, s), "node projection kernel");
   EdgeArgs ea{};
   ea.E = num_edges;
   ea.N = num_nodes;
@@ -641,7 +663,7 @@ int amber_mpn_block(const AmberMpnDesc* desc, const float* params, const float* 
   na.head = w.head;
   na.tail = w.tail;
   fill_node_update(na, *desc, lay, step, params, packed);
-  HIP_TRY(launch_node(L, na, s), "node kernel");
+  HIP_TRY(run_node(*desc, na, s), "node kernel");
   return AMBER_OK;
 }
 

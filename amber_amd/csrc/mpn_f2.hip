@@ -123,6 +123,142 @@ DEVINL void kstep(Tile<L>& acc, const half8 ah, const half8 al, const unsigned c
   for (int fb = 0; fb < NFB; ++fb) acc.a[fb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[fb], acc.a[fb], 0, 0, 0);
 }
 
+
+// lane-constant byte offsets into the wave's LDS window
+struct WinOff {
+  int ew[4];     // row-piece image ([row][32 features] fp16, 64-byte rows, 16-byte slots XOR-swizzled by (row >> 2) & 3):
+                 // writer, row it*8 + lane/8, 8-byte piece lane % 8
+  int er[2];     // ... reader (A operand of k-step sp): row n, slot 2 sp + h
+  int hw[4];     // transposed image ([feature][32 rows] fp16, 64-byte rows, 8-byte units XOR-swizzled by (row >> 1) & 7):
+                 // writer, image row n, unit 2 g + h
+  int hr[2][2];  // ... transposing reader: k-step sp, chunk t; this lane supplies image row 16 sp + 8 h + 4 t + q, unit 4 colblk + p
+};
+DEVINL WinOff make_win_off(int lane) {
+  WinOff o;
+  const int n = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int rr = it * 8 + (lane >> 3), q = lane & 7;
+    o.ew[it] = rr * 64 + ((((q >> 1) ^ ((rr >> 2) & 3))) << 4) + ((q & 1) << 3);
+  }
+#pragma unroll
+  for (int sp = 0; sp < 2; ++sp) o.er[sp] = n * 64 + ((((2 * sp + h) ^ ((n >> 2) & 3))) << 4);
+#pragma unroll
+  for (int g = 0; g < 4; ++g) o.hw[g] = n * 64 + ((((2 * g + h) ^ ((n >> 1) & 7))) << 3);
+  const int gl = lane & 15, q = gl >> 2, p = gl & 3, colblk = (lane >> 4) & 1;
+#pragma unroll
+  for (int sp = 0; sp < 2; ++sp)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int row = 16 * sp + 8 * h + 4 * t + q;
+      o.hr[sp][t] = row * 64 + ((((4 * colblk + p) ^ ((row >> 1) & 7))) << 3);
+    }
+  return o;
+}
+
+// acc += (tile * scale) x W^T for a tile held as whole row pieces (ELanding): 32 features a pass are split into hi/lo
+// fp16, written to the window as a [row][feature] image and read back as the A operand with ds_read_b128
+template <int L>
+DEVINL void gemm_rows(Tile<L>& acc, const ELanding<L>& la, float scale, unsigned char* win, const WinOff& o,
+                      const unsigned char* wl, int lane) {
+#pragma unroll
+  for (int ps = 0; ps < L / 32; ++ps) {
+    wave_sync();  // the previous readers of the window are done
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      half4 hi, lo;
+      split4(la.v[ps][it], scale, hi, lo);
+      *reinterpret_cast<half4*>(win + o.ew[it]) = hi;
+      *reinterpret_cast<half4*>(win + kLoPlane + o.ew[it]) = lo;
+    }
+    wave_sync();
+#pragma unroll
+    for (int sp = 0; sp < 2; ++sp) {
+      const half8 ah = *reinterpret_cast<const half8*>(win + o.er[sp]);
+      const half8 al = *reinterpret_cast<const half8*>(win + kLoPlane + o.er[sp]);
+      kstep<L>(acc, ah, al, wl, 2 * ps + sp, lane);
+    }
+  }
+}
+
+// acc += (tile * scale) x W^T for a tile in accumulator layout (feature per lane): 32 features a pass go through the
+// window as a [feature][row] image and come back as the A operand through the transposing read
+template <int L>
+DEVINL void gemm_acc(Tile<L>& acc, const Tile<L>& in, float scale, unsigned char* win, const WinOff& o,
+                     const unsigned char* wl, int lane) {
+#pragma unroll
+  for (int fb = 0; fb < L / 32; ++fb) {
+    wave_sync();
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 x;
+      x[0] = in.a[fb][4 * g + 0];
+      x[1] = in.a[fb][4 * g + 1];
+      x[2] = in.a[fb][4 * g + 2];
+      x[3] = in.a[fb][4 * g + 3];
+      half4 hi, lo;
+      split4(x, scale, hi, lo);
+      *reinterpret_cast<half4*>(win + o.hw[g]) = hi;
+      *reinterpret_cast<half4*>(win + kLoPlane + o.hw[g]) = lo;
+    }
+    wave_sync();
+#pragma unroll
+    for (int sp = 0; sp < 2; ++sp) {
+      const half4 a0 = lds_read_tr(win + o.hr[sp][0]), a1 = lds_read_tr(win + o.hr[sp][1]);
+      const half4 b0 = lds_read_tr(win + kLoPlane + o.hr[sp][0]), b1 = lds_read_tr(win + kLoPlane + o.hr[sp][1]);
+      half8 ah, al;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        ah[t] = a0[t];
+        ah[4 + t] = a1[t];
+        al[t] = b0[t];
+        al[4 + t] = b1[t];
+      }
+      kstep<L>(acc, ah, al, wl, 2 * fb + sp, lane);
+    }
+  }
+}
+
+template <int L>
+DEVINL float landing_absmax(const ELanding<L>& la) {
+  float m = 0.f;
+#pragma unroll
+  for (int ps = 0; ps < L / 32; ++ps)
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) m = fmaxf(m, fabsf(la.v[ps][it][t]));
+  return m;
+}
+// LayerNorm over the features of every row of a tile in accumulator layout: across the lanes of a half, one register a row
+template <int L>
+DEVINL void tile_layernorm_acc(Tile<L>& acc, const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int n) {
+  constexpr int NFB = L / 32;
+  float g[NFB], bt[NFB];
+#pragma unroll
+  for (int fb = 0; fb < NFB; ++fb) {
+    g[fb] = gamma[32 * fb + n];
+    bt[fb] = beta[32 * fb + n];
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    float s = acc.a[0][i];
+#pragma unroll
+    for (int fb = 1; fb < NFB; ++fb) s += acc.a[fb][i];
+    const float mean = half_sum(s) * (1.0f / L);
+    float q = 0.f;
+#pragma unroll
+    for (int fb = 0; fb < NFB; ++fb) {
+      const float dlt = acc.a[fb][i] - mean;
+      acc.a[fb][i] = dlt;
+      q += dlt * dlt;
+    }
+    const float rstd = __builtin_amdgcn_rsqf(half_sum(q) * (1.0f / L) + eps);  // v_rsq_f32: 1 ulp
+#pragma unroll
+    for (int fb = 0; fb < NFB; ++fb) acc.a[fb][i] = acc.a[fb][i] * rstd * g[fb] + bt[fb];
+  }
+}
+
 template <int L>
 __global__ __launch_bounds__(kF2Block) void edge_kernel_f2(const EdgeArgs a, const int64_t ntiles) {
   constexpr int NFB = L / 32;
@@ -140,32 +276,7 @@ __global__ __launch_bounds__(kF2Block) void edge_kernel_f2(const EdgeArgs a, con
   __syncthreads();
   unsigned char* win = smem + a.nl * MAT_BYTES + wave * kWinBytes;
 
-  // lane-constant LDS offsets
-  // e planes ([edge][32 features] fp16, 64-byte rows, 16-byte slots XOR-swizzled by (row >> 2) & 3)
-  int ew_off[4];  // writer: row it*8 + lane/8, 8-byte piece lane % 8
-#pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int rr = it * 8 + (lane >> 3), q = lane & 7;
-    ew_off[it] = rr * 64 + ((((q >> 1) ^ ((rr >> 2) & 3))) << 4) + ((q & 1) << 3);
-  }
-  int er_off[2];  // reader (A operand of k-step sp): row n, slot 2 sp + h
-#pragma unroll
-  for (int sp = 0; sp < 2; ++sp) er_off[sp] = n * 64 + ((((2 * sp + h) ^ ((n >> 2) & 3))) << 4);
-  // hidden-layer image ([feature][32 edges] fp16, 64-byte rows, 8-byte units XOR-swizzled by (row >> 1) & 7)
-  int hw_off[4];  // writer: row n, unit 2 g + h
-#pragma unroll
-  for (int g = 0; g < 4; ++g) hw_off[g] = n * 64 + ((((2 * g + h) ^ ((n >> 1) & 7))) << 3);
-  int hr_off[2][2];  // transposing reader: k-step sp, chunk t; this lane supplies row 16 sp + 8 h + 4 t + q, unit 4 colblk + p
-  {
-    const int gl = lane & 15, q = gl >> 2, p = gl & 3, colblk = (lane >> 4) & 1;
-#pragma unroll
-    for (int sp = 0; sp < 2; ++sp)
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const int row = 16 * sp + 8 * h + 4 * t + q;
-        hr_off[sp][t] = row * 64 + ((((4 * colblk + p) ^ ((row >> 1) & 7))) << 3);
-      }
-  }
+  const WinOff wo = make_win_off(lane);
   const float wsinv0 = a.w0e[L * L], wscale0 = a.w0e[L * L + 1];  // pack-time power-of-two weight scale (matrix header)
   const float mh0 = h == 0 ? 1.f : 0.f, mh1 = 1.f - mh0;
 
@@ -230,35 +341,9 @@ __global__ __launch_bounds__(kF2Block) void edge_kernel_f2(const EdgeArgs a, con
 
     // ---- layer 0: acc = (P_s + P_d) + W0e e, in the scaled domain ----
     float scale, inv;
-    {
-      float m = 0.f;
-#pragma unroll
-      for (int ps = 0; ps < NFB; ++ps)
-#pragma unroll
-        for (int it = 0; it < 4; ++it)
-#pragma unroll
-          for (int t = 0; t < 4; ++t) m = fmaxf(m, fabsf(la.v[ps][it][t]));
-      pow2_scale(wave_max(m), scale, inv);
-    }
+    pow2_scale(wave_max(landing_absmax<L>(la)), scale, inv);
     tile_scale<L>(acc, scale * wscale0);
-#pragma unroll
-    for (int ps = 0; ps < NFB; ++ps) {
-      wave_sync();  // the previous readers of the window are done
-#pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        half4 hi, lo;
-        split4(la.v[ps][it], scale, hi, lo);
-        *reinterpret_cast<half4*>(win + ew_off[it]) = hi;
-        *reinterpret_cast<half4*>(win + kLoPlane + ew_off[it]) = lo;
-      }
-      wave_sync();
-#pragma unroll
-      for (int sp = 0; sp < 2; ++sp) {
-        const half8 ah = *reinterpret_cast<const half8*>(win + er_off[sp]);
-        const half8 al = *reinterpret_cast<const half8*>(win + kLoPlane + er_off[sp]);
-        if (!DBG(8)) kstep<L>(acc, ah, al, smem, 2 * ps + sp, lane);
-      }
-    }
+    if (!DBG(8)) gemm_rows<L>(acc, la, scale, win, wo, smem, lane);
     // destination terms (rows repeat inside a tile: L1 / L2 hits) join after the contraction, when the landing
     // registers of e are free again
     {
@@ -287,37 +372,7 @@ __global__ __launch_bounds__(kF2Block) void edge_kernel_f2(const EdgeArgs a, con
           for (int i = 0; i < 16; ++i) nxt.a[fb][i] = b;
         }
       }
-#pragma unroll
-      for (int fb = 0; fb < NFB; ++fb) {
-        wave_sync();
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          f32x4 x;
-          x[0] = acc.a[fb][4 * g + 0];
-          x[1] = acc.a[fb][4 * g + 1];
-          x[2] = acc.a[fb][4 * g + 2];
-          x[3] = acc.a[fb][4 * g + 3];
-          half4 hi, lo;
-          split4(x, scale, hi, lo);
-          *reinterpret_cast<half4*>(win + hw_off[g]) = hi;
-          *reinterpret_cast<half4*>(win + kLoPlane + hw_off[g]) = lo;
-        }
-        wave_sync();
-#pragma unroll
-        for (int sp = 0; sp < 2; ++sp) {
-          const half4 a0 = lds_read_tr(win + hr_off[sp][0]), a1 = lds_read_tr(win + hr_off[sp][1]);
-          const half4 b0 = lds_read_tr(win + kLoPlane + hr_off[sp][0]), b1 = lds_read_tr(win + kLoPlane + hr_off[sp][1]);
-          half8 ah, al;
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            ah[t] = a0[t];
-            ah[4 + t] = a1[t];
-            al[t] = b0[t];
-            al[4 + t] = b1[t];
-          }
-          if (!DBG(8)) kstep<L>(nxt, ah, al, smem + l * MAT_BYTES, 2 * fb + sp, lane);
-        }
-      }
+      if (!DBG(8)) gemm_acc<L>(nxt, acc, scale, win, wo, smem + l * MAT_BYTES, lane);
       tile_scale<L>(nxt, inv * wg[L * L]);
       tile_act_fast<L>(nxt, a.act);
       acc = nxt;
@@ -334,31 +389,7 @@ __global__ __launch_bounds__(kF2Block) void edge_kernel_f2(const EdgeArgs a, con
       }
     }
     // ---- LayerNorm over the features of every edge: across the lanes of a half, one register per edge ----
-    if (a.layer_norm == AMBER_MODE_INNER && !DBG(64)) {
-      float g[NFB], bt[NFB];
-#pragma unroll
-      for (int fb = 0; fb < NFB; ++fb) {
-        g[fb] = a.gamma[32 * fb + n];
-        bt[fb] = a.beta[32 * fb + n];
-      }
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        float s = acc.a[0][i];
-#pragma unroll
-        for (int fb = 1; fb < NFB; ++fb) s += acc.a[fb][i];
-        const float mean = half_sum(s) * (1.0f / L);
-        float q = 0.f;
-#pragma unroll
-        for (int fb = 0; fb < NFB; ++fb) {
-          const float dlt = acc.a[fb][i] - mean;
-          acc.a[fb][i] = dlt;
-          q += dlt * dlt;
-        }
-        const float rstd = __builtin_amdgcn_rsqf(half_sum(q) * (1.0f / L) + a.eps);  // v_rsq_f32: 1 ulp
-#pragma unroll
-        for (int fb = 0; fb < NFB; ++fb) acc.a[fb][i] = acc.a[fb][i] * rstd * g[fb] + bt[fb];
-      }
-    }
+    if (a.layer_norm == AMBER_MODE_INNER && !DBG(64)) tile_layernorm_acc<L>(acc, a.gamma, a.beta, a.eps, n);
     // ---- stores of e' (two whole 128-byte row pieces per register) ----
     if (a.write_e || a.out_edge) {
       int pm = 0;
@@ -442,6 +473,257 @@ __global__ __launch_bounds__(kF2Block) void edge_kernel_f2(const EdgeArgs a, con
     }
     s0 = s1; d0 = d1;
     s1 = s2; d1 = d2;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// node kernel, same orientation: finish K6 (combine partial sums, divide by the in-degree), K7 (node MLP), K8
+// (residual + LayerNorm) and the next edge step's first-layer projections P_s / P_d.
+// reference: MessagePassingNodeModule.forward (src/mpn/message_passing_modules.py:61-72),
+//            MessagePassingBlock.forward (src/mpn/message_passing_block.py:123-128)
+//
+// A node tile is 32 consecutive rows; x and the aggregate arrive as whole row pieces, x', P_s and P_d leave straight
+// from the accumulator layout.  The update needs 2 + (nl - 1) weight matrices and the projections 2 more: at L = 128
+// only two of them (64 KB each) fit beside the waves' windows, so the workgroup's 8 waves walk the matrices together,
+// one PHASE per matrix, each wave on its own tile: while a phase contracts with the matrix in one LDS slot the next
+// matrix streams into the other slot by LDS-DMA (global_load_lds), and one workgroup barrier separates the phases.
+// When all matrices fit (L <= 64) they are loaded once and the phases run without barriers.
+// ---------------------------------------------------------------------------------------------------
+template <int L>
+__global__ __launch_bounds__(kF2Block) void node_kernel_f2(const NodeArgs a, const int64_t ntiles, const int resident) {
+  constexpr int NFB = L / 32;
+  constexpr int MAT_BYTES = L * L * 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = lane & 31, h = lane >> 5;
+  const int nu = a.do_update ? a.nl + 1 : 0;   // phases of the update: W0x, W0a, hidden layers
+  const int P = nu + (a.do_proj ? 2 : 0);      // phases per batch of tiles
+  // matrix of phase k (wave-uniform)
+  auto mat = [&](int k) -> const float* {
+    if (k < nu) return k == 0 ? a.w0x : (k == 1 ? a.w0a : a.layers[k - 1].w);
+    return k == nu ? a.w0s : a.w0d;
+  };
+  // this wave's share of one matrix, global -> LDS slot, no registers (1 KB per instruction)
+  auto stream_in = [&](const float* src, int slot) {
+    int lo16 = lane * 16;  // opaque: hoisted out of the batch loop, the per-matrix source addresses would be spilled
+    asm volatile("" : "+v"(lo16));
+    for (int j = wave; j < MAT_BYTES / 1024; j += kF2Waves)
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(reinterpret_cast<const unsigned char*>(src) + j * 1024 + lo16),
+          (__attribute__((address_space(3))) void*)(smem + slot * MAT_BYTES + j * 1024), 16, 0, 0);
+  };
+  const int nslots = resident ? P : 2;
+  unsigned char* win = smem + nslots * MAT_BYTES + wave * kWinBytes;
+  const WinOff wo = make_win_off(lane);
+
+  const int64_t xcd = blockIdx.x & 7, local = blockIdx.x >> 3, bpx = gridDim.x >> 3;
+  const int64_t tiles_per_xcd = (ntiles + 7) >> 3;
+  const int64_t t_begin = xcd * tiles_per_xcd;
+  const int64_t t_end = t_begin + tiles_per_xcd < ntiles ? t_begin + tiles_per_xcd : ntiles;
+  const int64_t stride = bpx * kF2Waves;
+  const int64_t first = t_begin + local * kF2Waves;
+  const int64_t nbatch = first < t_end ? (t_end - first + stride - 1) / stride : 0;  // the same for every wave of the workgroup
+  if (nbatch == 0) return;
+
+  if (resident) {
+    for (int k = 0; k < P; ++k) stream_in(mat(k), k);
+    __syncthreads();
+  } else {
+    stream_in(mat(0), 0);
+  }
+  int gphase = 0;  // phases begun so far (ring mode: slot = gphase & 1)
+  const int64_t total_phases = nbatch * P;
+  // begin a phase: returns the LDS address of its matrix.  Ring mode: the barrier tells that every wave has left the
+  // previous phase (whose slot is refilled now) and, with the wait in front of it, that this phase's matrix has landed.
+  auto begin_phase = [&](int k) -> const unsigned char* {
+    int slot = k;
+    if (!resident) {
+      __syncthreads();
+      slot = gphase & 1;
+      if (gphase + 1 < total_phases) stream_in(mat(k + 1 < P ? k + 1 : 0), slot ^ 1);
+    }
+    ++gphase;
+    return smem + slot * MAT_BYTES;
+  };
+
+  for (int64_t b = 0; b < nbatch; ++b) {
+    // A wave without a tile of its own keeps the workgroup's barriers: it recomputes the last tile of the range and
+    // stores nothing (nstore = 0) - cheaper for the register allocator than guarding every phase.
+    const int64_t mytile = first + b * stride + wave;
+    const int64_t tile = mytile < t_end ? mytile : t_end - 1;
+    const int64_t n0 = tile * kTile;
+    const int nvalid = (a.N - n0) < kTile ? static_cast<int>(a.N - n0) : kTile;  // rows of the tile that exist (>= 1)
+    const int nstore = mytile < t_end ? nvalid : 0;                              // rows this wave stores
+    const int rlim = nvalid - 1;
+    const float* const xt = a.x_in + n0 * L;
+    int hq = 4 * h * L + n, nq = n, lq = lane;
+    asm volatile("" : "+v"(hq), "+v"(nq), "+v"(lq));
+    Tile<L> v;  // the tile's node features in accumulator layout (after the update: x')
+    int k = 0;
+    if (a.do_update) {
+      Tile<L> acc;
+      float scale, inv;
+      {
+        // ---- whole row pieces of x ----
+        ELanding<L> lx;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int r = it * 8 + (lq >> 3);
+          const int rc = r < rlim ? r : rlim;  // rows beyond the end repeat the last node and are never stored
+          const f32x4* px = reinterpret_cast<const f32x4*>(xt + static_cast<unsigned>(rc * L)) + (lq & 7);
+#pragma unroll
+          for (int ps = 0; ps < NFB; ++ps) lx.v[ps][it] = px[ps * 8];
+        }
+        pow2_scale(wave_max(landing_absmax<L>(lx)), scale, inv);
+        const float bs = scale * a.w0x[L * L + 1];
+#pragma unroll
+        for (int fb = 0; fb < NFB; ++fb) {
+          const float bv = a.b0[32 * fb + nq] * bs;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc.a[fb][i] = bv;
+        }
+        const unsigned char* wl = begin_phase(k++);
+        gemm_rows<L>(acc, lx, scale, win, wo, wl, lane);
+      }
+      {
+        // ---- whole row pieces of the aggregate: sums of the edge kernel -> mean ----
+        ELanding<L> lg;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int r = it * 8 + (lq >> 3);
+          const int64_t node = n0 + (r < rlim ? r : rlim);
+          const int r0 = a.rowptr[node], r1 = a.rowptr[node + 1];
+          const int deg = r1 - r0;
+          const f32x4* pg = reinterpret_cast<const f32x4*>(a.agg + node * L) + (lq & 7);
+#pragma unroll
+          for (int ps = 0; ps < NFB; ++ps) lg.v[ps][it] = pg[ps * 8];
+          if (deg > 0) {
+            const int t0 = r0 >> a.red_shift, t1 = (r1 - 1) >> a.red_shift;
+            if (t0 != t1) {
+              // the row was cut by tile boundaries of the edge kernel: tail of its first tile, then heads, in tile order
+              const f32x4* pt = reinterpret_cast<const f32x4*>(a.tail + static_cast<int64_t>(t0) * L) + (lq & 7);
+#pragma unroll
+              for (int ps = 0; ps < NFB; ++ps) lg.v[ps][it] = pt[ps * 8];
+              for (int t = t0 + 1; t <= t1; ++t) {
+                const f32x4* ph = reinterpret_cast<const f32x4*>(a.head + static_cast<int64_t>(t) * L) + (lq & 7);
+#pragma unroll
+                for (int ps = 0; ps < NFB; ++ps) lg.v[ps][it] += ph[ps * 8];
+              }
+            }
+          }
+          // mean; zero in-degree -> 0 (scatter_mean semantics; that row of agg was never written)
+          const float rd = 1.0f / static_cast<float>(deg > 1 ? deg : 1);
+#pragma unroll
+          for (int ps = 0; ps < NFB; ++ps)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) lg.v[ps][it][t] = deg > 0 ? lg.v[ps][it][t] * rd : 0.f;
+        }
+        // x and the aggregate feed one accumulator (W0x and W0a share their pack-time scale): move the accumulator
+        // from x's power-of-two scale to the aggregate's (exact)
+        float sg, ig;
+        pow2_scale(wave_max(landing_absmax<L>(lg)), sg, ig);
+        tile_scale<L>(acc, sg * inv);
+        const unsigned char* wl = begin_phase(k++);
+        gemm_rows<L>(acc, lg, sg, win, wo, wl, lane);
+        tile_scale<L>(acc, ig * a.w0x[L * L]);
+        tile_act_fast<L>(acc, a.act);
+      }
+#pragma unroll 1
+      for (int l = 1; l < a.nl; ++l) {
+        const unsigned char* wl = begin_phase(k++);
+        const float* wg = a.layers[l].w;
+        pow2_scale(wave_max(tile_absmax<L>(acc)), scale, inv);
+        Tile<L> nxt;
+        const float bs = scale * wg[L * L + 1];
+#pragma unroll
+        for (int fb = 0; fb < NFB; ++fb) {
+          const float bv = a.layers[l].b[32 * fb + nq] * bs;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) nxt.a[fb][i] = bv;
+        }
+        gemm_acc<L>(nxt, acc, scale, win, wo, wl, lane);
+        tile_scale<L>(nxt, inv * wg[L * L]);
+        tile_act_fast<L>(nxt, a.act);
+        acc = nxt;
+      }
+      // order of message_passing_block.py:124-125: inner residual, inner LayerNorm
+      if (a.residual == AMBER_MODE_INNER) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const unsigned off = nvalid == kTile ? static_cast<unsigned>(hq + (8 * (i >> 2) + (i & 3)) * L)
+                                               : static_cast<unsigned>(min(8 * (i >> 2) + (i & 3) + 4 * h, rlim) * L + n);
+#pragma unroll
+          for (int fb = 0; fb < NFB; ++fb) acc.a[fb][i] += xt[off + 32 * fb];
+        }
+      }
+      if (a.layer_norm == AMBER_MODE_INNER) tile_layernorm_acc<L>(acc, a.gamma, a.beta, a.eps, nq);
+      v = acc;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const unsigned off = static_cast<unsigned>(min(8 * (i >> 2) + (i & 3) + 4 * h, rlim) * L + n);
+#pragma unroll
+        for (int fb = 0; fb < NFB; ++fb) v.a[fb][i] = xt[off + 32 * fb];
+      }
+    }
+    // store a tile in accumulator layout as rows n0 .. n0 + nvalid - 1 of `out`
+    auto store_tile = [&](float* out, const Tile<L>& t) {
+      float* const ot = out + n0 * L;
+      if (nstore == kTile) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const unsigned off = static_cast<unsigned>(hq + (8 * (i >> 2) + (i & 3)) * L);
+#pragma unroll
+          for (int fb = 0; fb < NFB; ++fb) ot[off + 32 * fb] = t.a[fb][i];
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          if (8 * (i >> 2) + (i & 3) + 4 * h < nstore) {
+#pragma unroll
+            for (int fb = 0; fb < NFB; ++fb) ot[static_cast<unsigned>(hq + (8 * (i >> 2) + (i & 3)) * L) + 32 * fb] = t.a[fb][i];
+          }
+        }
+      }
+    };
+    if (a.x_out && a.do_update) store_tile(a.x_out, v);
+    if (a.do_proj) {
+      float scale, inv;
+      pow2_scale(wave_max(tile_absmax<L>(v)), scale, inv);
+      {
+        const unsigned char* wl = begin_phase(k++);
+        Tile<L> acc;
+        tile_zero<L>(acc);
+        gemm_acc<L>(acc, v, scale, win, wo, wl, lane);
+        tile_scale<L>(acc, inv * a.w0s[L * L]);
+        store_tile(a.Ps, acc);
+      }
+      {
+        const unsigned char* wl = begin_phase(k++);
+        // x' again, from memory (this wave's own stores of a moment ago, or the input rows): kept in registers across
+        // the previous phase it would push the kernel over its 256 registers
+        {
+          const float* const vt = (a.do_update ? a.x_out : a.x_in) + n0 * L;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const unsigned off = static_cast<unsigned>(min(8 * (i >> 2) + (i & 3) + 4 * h, rlim) * L + nq);
+#pragma unroll
+            for (int fb = 0; fb < NFB; ++fb) v.a[fb][i] = vt[off + 32 * fb];
+          }
+        }
+        Tile<L> acc;
+        const float bs = scale * a.w0d[L * L + 1];
+#pragma unroll
+        for (int fb = 0; fb < NFB; ++fb) {
+          const float bv = a.b0e[32 * fb + nq] * bs;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc.a[fb][i] = bv;
+        }
+        gemm_acc<L>(acc, v, scale, win, wo, wl, lane);
+        tile_scale<L>(acc, inv * a.w0d[L * L]);
+        store_tile(a.Pd, acc);
+      }
+    }
   }
 }
 
@@ -532,6 +814,36 @@ hipError_t launch_edge_f2(int L, const EdgeArgs& a, int num_cus, hipStream_t s) 
     case 32: return launch_edge_f2_t<32>(a, num_cus, s);
     case 64: return launch_edge_f2_t<64>(a, num_cus, s);
     case 128: return launch_edge_f2_t<128>(a, num_cus, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+bool node_f2_supported(int L, int act, int residual, int layer_norm) {
+  return (act == AMBER_ACT_RELU || act == AMBER_ACT_LEAKYRELU) && residual != AMBER_MODE_OUTER && layer_norm != AMBER_MODE_OUTER;
+}
+
+template <int L>
+static hipError_t launch_node_f2_t(const NodeArgs& a, int num_cus, hipStream_t s) {
+  const int64_t ntiles = (a.N + kTile - 1) / kTile;
+  if (ntiles == 0 || (!a.do_update && !a.do_proj)) return hipSuccess;
+  const int P = (a.do_update ? a.nl + 1 : 0) + (a.do_proj ? 2 : 0);
+  const size_t mat = static_cast<size_t>(L) * L * 4, wins = static_cast<size_t>(kF2Waves) * kWinBytes;
+  const int resident = P * mat + wins <= 160 * 1024 ? 1 : 0;
+  const size_t lds = (resident ? P : 2) * mat + wins;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(node_kernel_f2<L>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     static_cast<int>(lds));
+  if (e != hipSuccess) return e;
+  int64_t grid = (num_cus / 8) * 8;  // one persistent workgroup per CU, a multiple of the 8 XCDs
+  if (grid < 8) grid = 8;
+  hipLaunchKernelGGL(node_kernel_f2<L>, dim3(static_cast<unsigned>(grid)), dim3(kF2Block), lds, s, a, ntiles, resident);
+  return hipGetLastError();
+}
+
+hipError_t launch_node_f2(int L, const NodeArgs& a, int num_cus, hipStream_t s) {
+  switch (L) {
+    case 32: return launch_node_f2_t<32>(a, num_cus, s);
+    case 64: return launch_node_f2_t<64>(a, num_cus, s);
+    case 128: return launch_node_f2_t<128>(a, num_cus, s);
     default: return hipErrorInvalidValue;
   }
 }

@@ -109,6 +109,9 @@ hipError_t launch_pack_h(int L, const float* W, int ld, int col0, int scale_col0
 hipError_t launch_pack_f2(int L, const float* W, int ld, int col0, int scale_col0, int scale_cols, float* out, hipStream_t s);
 hipError_t launch_edge_f2(int L, const EdgeArgs& a, int num_cus, hipStream_t s);
 bool edge_f2_supported(int L, int nl, int act, int residual, int layer_norm);
+// feature-per-lane node kernel (update + next-step projections; weights as B operand, W0x / W0a sharing one scale)
+hipError_t launch_node_f2(int L, const NodeArgs& a, int num_cus, hipStream_t s);
+bool node_f2_supported(int L, int act, int residual, int layer_norm);
 hipError_t launch_segment_mean(const float* vals, const int32_t* rowptr, int64_t N, int L, float* out, hipStream_t s);
 hipError_t launch_permute_rows(const float* in, const int32_t* perm, int64_t rows, int width, int gather, float* out,
                                hipStream_t s);
