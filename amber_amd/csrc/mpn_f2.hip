@@ -264,7 +264,7 @@ __global__ __launch_bounds__(kF2Block) void edge_kernel_f2(const EdgeArgs a, con
   constexpr int NFB = L / 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int MAT_BYTES = L * L * 4;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave id as a scalar
   const int n = lane & 31, h = lane >> 5;
 
   // all layer weights (hi/lo fp16, B-operand order) into LDS, once per workgroup
@@ -494,7 +494,7 @@ __global__ __launch_bounds__(kF2Block) void node_kernel_f2(const NodeArgs a, con
   constexpr int NFB = L / 32;
   constexpr int MAT_BYTES = L * L * 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave id as a scalar
   const int n = lane & 31, h = lane >> 5;
   const int nu = a.do_update ? a.nl + 1 : 0;   // phases of the update: W0x, W0a, hidden layers
   const int P = nu + (a.do_proj ? 2 : 0);      // phases per batch of tiles
@@ -509,7 +509,7 @@ __global__ __launch_bounds__(kF2Block) void node_kernel_f2(const NodeArgs a, con
     asm volatile("" : "+v"(lo16));
     for (int j = wave; j < MAT_BYTES / 1024; j += kF2Waves)
       __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)(reinterpret_cast<const unsigned char*>(src) + j * 1024 + lo16),
+          (const __attribute__((address_space(1))) void*)(reinterpret_cast<const unsigned char*>(src) + j * 1024 + static_cast<unsigned>(lo16)),
           (__attribute__((address_space(3))) void*)(smem + slot * MAT_BYTES + j * 1024), 16, 0, 0);
   };
   const int nslots = resident ? P : 2;
@@ -525,22 +525,33 @@ __global__ __launch_bounds__(kF2Block) void node_kernel_f2(const NodeArgs a, con
   const int64_t nbatch = first < t_end ? (t_end - first + stride - 1) / stride : 0;  // the same for every wave of the workgroup
   if (nbatch == 0) return;
 
+  // Ring mode hand-over without draining the stores: vector memory operations complete in issue order, so each wave
+  // issues one ordinary "marker" load right behind its share of the LDS-DMA and waits for that load (a counted
+  // s_waitcnt that leaves the younger stores in flight) before the barrier that opens the phase reading the slot.
+  float marker = 0.f;
+  auto marker_load = [&](const float* src) { marker = src[lane]; };
   if (resident) {
     for (int k = 0; k < P; ++k) stream_in(mat(k), k);
     __syncthreads();
   } else {
     stream_in(mat(0), 0);
+    marker_load(mat(0));
   }
   int gphase = 0;  // phases begun so far (ring mode: slot = gphase & 1)
   const int64_t total_phases = nbatch * P;
   // begin a phase: returns the LDS address of its matrix.  Ring mode: the barrier tells that every wave has left the
-  // previous phase (whose slot is refilled now) and, with the wait in front of it, that this phase's matrix has landed.
+  // previous phase (whose slot is refilled now) and that every wave's share of this phase's matrix has landed.
   auto begin_phase = [&](int k) -> const unsigned char* {
     int slot = k;
     if (!resident) {
-      __syncthreads();
+      asm volatile("" ::"v"(marker));  // the compiler waits for the marker load here: this wave's DMA share is in LDS
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       slot = gphase & 1;
-      if (gphase + 1 < total_phases) stream_in(mat(k + 1 < P ? k + 1 : 0), slot ^ 1);
+      if (gphase + 1 < total_phases) {
+        const float* nm = mat(k + 1 < P ? k + 1 : 0);
+        stream_in(nm, slot ^ 1);
+        marker_load(nm);
+      }
     }
     ++gphase;
     return smem + slot * MAT_BYTES;
