@@ -265,6 +265,8 @@ hipError_t run_edge(const AmberMpnDesc& d, EdgeArgs& ea, hipStream_t s) {
 hipError_t run_node(const AmberMpnDesc& d, const NodeArgs& na, hipStream_t s) {
   if (!na.fast) return launch_node(d.latent, na, s);
   NodeArgs u = na;
+  const char* dbg = getenv("AMBER_MPN_DBG");
+  u.dbg = dbg ? atoi(dbg) : 0;
   u.n_dense = 0;
   u.do_readout = 0;
   u.dense_out = nullptr;

@@ -545,12 +545,14 @@ __global__ __launch_bounds__(kF2Block) void node_kernel_f2(const NodeArgs a, con
     int slot = k;
     if (!resident) {
       asm volatile("" ::"v"(marker));  // the compiler waits for the marker load here: this wave's DMA share is in LDS
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (!DBG(512)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       slot = gphase & 1;
       if (gphase + 1 < total_phases) {
         const float* nm = mat(k + 1 < P ? k + 1 : 0);
-        stream_in(nm, slot ^ 1);
-        marker_load(nm);
+        if (!DBG(1024)) {
+          stream_in(nm, slot ^ 1);
+          marker_load(nm);
+        }
       }
     }
     ++gphase;
@@ -594,40 +596,62 @@ __global__ __launch_bounds__(kF2Block) void node_kernel_f2(const NodeArgs a, con
           for (int i = 0; i < 16; ++i) acc.a[fb][i] = bv;
         }
         const unsigned char* wl = begin_phase(k++);
-        gemm_rows<L>(acc, lx, scale, win, wo, wl, lane);
+        if (!DBG(256)) gemm_rows<L>(acc, lx, scale, win, wo, wl, lane);
       }
       {
         // ---- whole row pieces of the aggregate: sums of the edge kernel -> mean ----
         ELanding<L> lg;
+        // Three rounds of loads, each issued for all four row pieces of the lane before any is used: rowptr; the row
+        // of sums (agg, or the tail slot when tile boundaries of the edge kernel cut the row); the first head slot of
+        // a cut row.  Rows cut more than once (longer than a tile) add their further heads in a loop.
+        int dg[4], tf[4], tl[4];
+        int64_t nd[4];
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
           const int r = it * 8 + (lq >> 3);
-          const int64_t node = n0 + (r < rlim ? r : rlim);
-          const int r0 = a.rowptr[node], r1 = a.rowptr[node + 1];
-          const int deg = r1 - r0;
-          const f32x4* pg = reinterpret_cast<const f32x4*>(a.agg + node * L) + (lq & 7);
+          nd[it] = n0 + (r < rlim ? r : rlim);
+          const int r0 = a.rowptr[nd[it]], r1 = a.rowptr[nd[it] + 1];
+          dg[it] = r1 - r0;
+          tf[it] = r0 >> a.red_shift;
+          tl[it] = dg[it] > 0 && !DBG(2048) ? (r1 - 1) >> a.red_shift : tf[it];
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const float* src = tl[it] != tf[it] ? a.tail + static_cast<int64_t>(tf[it]) * L : a.agg + nd[it] * L;
+          const f32x4* pg = reinterpret_cast<const f32x4*>(src) + (lq & 7);
 #pragma unroll
           for (int ps = 0; ps < NFB; ++ps) lg.v[ps][it] = pg[ps * 8];
-          if (deg > 0) {
-            const int t0 = r0 >> a.red_shift, t1 = (r1 - 1) >> a.red_shift;
-            if (t0 != t1) {
-              // the row was cut by tile boundaries of the edge kernel: tail of its first tile, then heads, in tile order
-              const f32x4* pt = reinterpret_cast<const f32x4*>(a.tail + static_cast<int64_t>(t0) * L) + (lq & 7);
+        }
+        {
+          ELanding<L> hd;
 #pragma unroll
-              for (int ps = 0; ps < NFB; ++ps) lg.v[ps][it] = pt[ps * 8];
-              for (int t = t0 + 1; t <= t1; ++t) {
-                const f32x4* ph = reinterpret_cast<const f32x4*>(a.head + static_cast<int64_t>(t) * L) + (lq & 7);
+          for (int it = 0; it < 4; ++it) {
 #pragma unroll
-                for (int ps = 0; ps < NFB; ++ps) lg.v[ps][it] += ph[ps * 8];
-              }
+            for (int ps = 0; ps < NFB; ++ps) hd.v[ps][it] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (tl[it] != tf[it]) {
+              const f32x4* ph = reinterpret_cast<const f32x4*>(a.head + static_cast<int64_t>(tf[it] + 1) * L) + (lq & 7);
+#pragma unroll
+              for (int ps = 0; ps < NFB; ++ps) hd.v[ps][it] = ph[ps * 8];
             }
           }
+#pragma unroll
+          for (int it = 0; it < 4; ++it)
+#pragma unroll
+            for (int ps = 0; ps < NFB; ++ps) lg.v[ps][it] += hd.v[ps][it];
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          for (int t = tf[it] + 2; t <= tl[it]; ++t) {
+            const f32x4* ph = reinterpret_cast<const f32x4*>(a.head + static_cast<int64_t>(t) * L) + (lq & 7);
+#pragma unroll
+            for (int ps = 0; ps < NFB; ++ps) lg.v[ps][it] += ph[ps * 8];
+          }
           // mean; zero in-degree -> 0 (scatter_mean semantics; that row of agg was never written)
-          const float rd = 1.0f / static_cast<float>(deg > 1 ? deg : 1);
+          const float rd = 1.0f / static_cast<float>(dg[it] > 1 ? dg[it] : 1);
 #pragma unroll
           for (int ps = 0; ps < NFB; ++ps)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) lg.v[ps][it][t] = deg > 0 ? lg.v[ps][it][t] * rd : 0.f;
+            for (int t = 0; t < 4; ++t) lg.v[ps][it][t] = dg[it] > 0 ? lg.v[ps][it][t] * rd : 0.f;
         }
         // x and the aggregate feed one accumulator (W0x and W0a share their pack-time scale): move the accumulator
         // from x's power-of-two scale to the aggregate's (exact)
@@ -635,7 +659,7 @@ __global__ __launch_bounds__(kF2Block) void node_kernel_f2(const NodeArgs a, con
         pow2_scale(wave_max(landing_absmax<L>(lg)), sg, ig);
         tile_scale<L>(acc, sg * inv);
         const unsigned char* wl = begin_phase(k++);
-        gemm_rows<L>(acc, lg, sg, win, wo, wl, lane);
+        if (!DBG(256)) gemm_rows<L>(acc, lg, sg, win, wo, wl, lane);
         tile_scale<L>(acc, ig * a.w0x[L * L]);
         tile_act_fast<L>(acc, a.act);
       }
@@ -652,7 +676,7 @@ __global__ __launch_bounds__(kF2Block) void node_kernel_f2(const NodeArgs a, con
 #pragma unroll
           for (int i = 0; i < 16; ++i) nxt.a[fb][i] = bv;
         }
-        gemm_acc<L>(nxt, acc, scale, win, wo, wl, lane);
+        if (!DBG(256)) gemm_acc<L>(nxt, acc, scale, win, wo, wl, lane);
         tile_scale<L>(nxt, inv * wg[L * L]);
         tile_act_fast<L>(nxt, a.act);
         acc = nxt;
@@ -667,7 +691,7 @@ __global__ __launch_bounds__(kF2Block) void node_kernel_f2(const NodeArgs a, con
           for (int fb = 0; fb < NFB; ++fb) acc.a[fb][i] += xt[off + 32 * fb];
         }
       }
-      if (a.layer_norm == AMBER_MODE_INNER) tile_layernorm_acc<L>(acc, a.gamma, a.beta, a.eps, nq);
+      if (a.layer_norm == AMBER_MODE_INNER && !DBG(4096)) tile_layernorm_acc<L>(acc, a.gamma, a.beta, a.eps, nq);
       v = acc;
     } else {
 #pragma unroll
@@ -705,7 +729,7 @@ __global__ __launch_bounds__(kF2Block) void node_kernel_f2(const NodeArgs a, con
         const unsigned char* wl = begin_phase(k++);
         Tile<L> acc;
         tile_zero<L>(acc);
-        gemm_acc<L>(acc, v, scale, win, wo, wl, lane);
+        if (!DBG(256)) gemm_acc<L>(acc, v, scale, win, wo, wl, lane);
         tile_scale<L>(acc, inv * a.w0s[L * L]);
         store_tile(a.Ps, acc);
       }
@@ -730,7 +754,7 @@ __global__ __launch_bounds__(kF2Block) void node_kernel_f2(const NodeArgs a, con
 #pragma unroll
           for (int i = 0; i < 16; ++i) acc.a[fb][i] = bv;
         }
-        gemm_acc<L>(acc, v, scale, win, wo, wl, lane);
+        if (!DBG(256)) gemm_acc<L>(acc, v, scale, win, wo, wl, lane);
         tile_scale<L>(acc, inv * a.w0d[L * L]);
         store_tile(a.Pd, acc);
       }

@@ -91,6 +91,7 @@ struct NodeArgs {
   const float* br;        // [1]
   const int32_t* out_index;  // [N] or nullptr
   float* out;
+  int32_t dbg;            // experiment switches (AMBER_MPN_DBG), 0 in production
 };
 
 hipError_t launch_edge(int L, const EdgeArgs& a, hipStream_t s);
