@@ -393,10 +393,16 @@ int forward_impl(const AmberMpnDesc* desc, const float* params, const float* pac
 
   rc = run_embedding(d, lay.node_embed, d.in_node_features, params, packed, x, N, nullptr, w.x, s, tm);
   if (rc) return rc;
-  rc = run_embedding(d, lay.edge_embed, d.in_edge_features, params, packed, edge_attr, E, perm, w.e, s, tm);
-  if (rc) return rc;
-
   const int iters = d.num_steps * d.num_step_repeats;
+  // The linear (or constant) edge embedding of few raw features is fused into the first edge step: its rows are
+  // computed there on the fly and e is first written by that step.
+  const bool fuse_edge_embed = iters > 0 && use_fast_edge(d) && d.in_edge_features <= kMaxFusedEmbed &&
+                               (d.in_edge_features == 0 || d.embed_layers == 0) && !getenv("AMBER_MPN_NO_FUSED_EMBED");
+  if (!fuse_edge_embed) {
+    rc = run_embedding(d, lay.edge_embed, d.in_edge_features, params, packed, edge_attr, E, perm, w.e, s, tm);
+    if (rc) return rc;
+  }
+
   const bool want_head = d.has_head && out_sizing;
   if (iters == 0) {
     NodeArgs a{};
@@ -445,6 +451,13 @@ int forward_impl(const AmberMpnDesc* desc, const float* params, const float* pac
     ea.agg = w.agg;
     ea.head = w.head;
     ea.tail = w.tail;
+    if (it == 0 && fuse_edge_embed) {
+      ea.emb_on = 1;
+      ea.emb_f = d.in_edge_features;
+      ea.emb_attr = edge_attr;
+      ea.emb_w = d.in_edge_features > 0 ? params + lay.edge_embed.W[0] : nullptr;
+      ea.emb_b = params + lay.edge_embed.B[0];
+    }
     ea.write_e = last ? 0 : 1;  // after the last step only the aggregate (and out_edge, if asked for) is needed
     ea.out_edge = last ? out_edge : nullptr;
     tm.begin(AMBER_KC_EDGE);
@@ -635,7 +648,6 @@ int amber_mpn_block(const AmberMpnDesc* desc, const float* params, const float* 
   const Layout lay = build_layout(*desc);
   const Workspace w = carve(*desc, num_nodes, num_edges, aligned_ws(workspace));
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const int L = desc->latent;
   NodeArgs pa{};
   pa.N = num_nodes;
   pa.x_in = x_latent;

@@ -259,7 +259,8 @@ DEVINL void tile_layernorm_acc(Tile<L>& acc, const float* __restrict__ gamma, co
   }
 }
 
-template <int L>
+// EMB: first step with the linear edge embedding fused in (e is computed on the fly instead of read)
+template <int L, bool EMB>
 __global__ __launch_bounds__(kF2Block) void edge_kernel_f2(const EdgeArgs a, const int64_t ntiles) {
   constexpr int NFB = L / 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -310,14 +311,52 @@ __global__ __launch_bounds__(kF2Block) void edge_kernel_f2(const EdgeArgs a, con
     // loop they would occupy dozens of registers for its whole length.
     int hq = 4 * h * L + n, nq = n;
     asm volatile("" : "+v"(hq), "+v"(nq));
+    // ---- first step with the edge embedding fused in: the rows of e are computed, not read (K1: Embedding.forward,
+    // src/mpn/common/embedding.py:44-54, linear form) - directly in accumulator layout ----
+    float eav[kMaxFusedEmbed] = {0.f, 0.f, 0.f, 0.f};  // lane c (both halves): raw features of tile row c
+    if (EMB && a.emb_f > 0) {
+      int64_t p = p0 + n;
+      if (p > a.E - 1) p = a.E - 1;
+      const float* pa = a.emb_attr + static_cast<int64_t>(a.perm[p]) * a.emb_f;
+#pragma unroll
+      for (int k = 0; k < kMaxFusedEmbed; ++k)
+        if (k < a.emb_f) eav[k] = pa[k];
+    }
+    auto embed_tile = [&](Tile<L>& t) {
+      float wq[NFB][kMaxFusedEmbed], bq[NFB];
+#pragma unroll
+      for (int fb = 0; fb < NFB; ++fb) {
+        bq[fb] = a.emb_b[32 * fb + nq];
+#pragma unroll
+        for (int k = 0; k < kMaxFusedEmbed; ++k) wq[fb][k] = k < a.emb_f ? a.emb_w[(32 * fb + nq) * a.emb_f + k] : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int r = 8 * (i >> 2) + (i & 3) + 4 * h;
+        float ev[kMaxFusedEmbed];
+#pragma unroll
+        for (int k = 0; k < kMaxFusedEmbed; ++k)
+          if (k < a.emb_f) ev[k] = __shfl(eav[k], r);  // wave-uniform guard
+#pragma unroll
+        for (int fb = 0; fb < NFB; ++fb) {
+          float v = bq[fb];
+#pragma unroll
+          for (int k = 0; k < kMaxFusedEmbed; ++k)
+            if (k < a.emb_f) v = fmaf(ev[k], wq[fb][k], v);  // k ascending, as the embed kernel
+          t.a[fb][i] = v;
+        }
+      }
+    };
     // ---- streamed e rows (whole row pieces) ----
     ELanding<L> la;
+    if constexpr (!EMB) {
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int r = it * 8 + (lane >> 3);
-      const f32x4* p = reinterpret_cast<const f32x4*>(et + static_cast<unsigned>((r < rlim ? r : rlim) * L)) + (lane & 7);
+      for (int it = 0; it < 4; ++it) {
+        const int r = it * 8 + (lane >> 3);
+        const f32x4* p = reinterpret_cast<const f32x4*>(et + static_cast<unsigned>((r < rlim ? r : rlim) * L)) + (lane & 7);
 #pragma unroll
-      for (int ps = 0; ps < NFB; ++ps) la.v[ps][it] = p[ps * 8];
+        for (int ps = 0; ps < NFB; ++ps) la.v[ps][it] = p[ps * 8];
+      }
     }
     // ---- gathered first-layer terms, straight into the accumulator layout ----
     Tile<L> acc;
@@ -341,9 +380,17 @@ __global__ __launch_bounds__(kF2Block) void edge_kernel_f2(const EdgeArgs a, con
 
     // ---- layer 0: acc = (P_s + P_d) + W0e e, in the scaled domain ----
     float scale, inv;
-    pow2_scale(wave_max(landing_absmax<L>(la)), scale, inv);
-    tile_scale<L>(acc, scale * wscale0);
-    if (!DBG(8)) gemm_rows<L>(acc, la, scale, win, wo, smem, lane);
+    if constexpr (EMB) {
+      Tile<L> e0;
+      embed_tile(e0);
+      pow2_scale(wave_max(tile_absmax<L>(e0)), scale, inv);
+      tile_scale<L>(acc, scale * wscale0);
+      gemm_acc<L>(acc, e0, scale, win, wo, smem, lane);
+    } else {
+      pow2_scale(wave_max(landing_absmax<L>(la)), scale, inv);
+      tile_scale<L>(acc, scale * wscale0);
+      if (!DBG(8)) gemm_rows<L>(acc, la, scale, win, wo, smem, lane);
+    }
     // destination terms (rows repeat inside a tile: L1 / L2 hits) join after the contraction, when the landing
     // registers of e are free again
     {
@@ -378,7 +425,11 @@ __global__ __launch_bounds__(kF2Block) void edge_kernel_f2(const EdgeArgs a, con
       acc = nxt;
     }
     // ---- residual: the rows of e again (this wave's own loads of a moment ago), now feature per lane ----
-    if (a.residual == AMBER_MODE_INNER && !DBG(1)) {
+    if (EMB && a.residual == AMBER_MODE_INNER) {
+      Tile<L> e0;
+      embed_tile(e0);
+      tile_add<L>(acc, e0);
+    } else if (!EMB && a.residual == AMBER_MODE_INNER && !DBG(1)) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         // rows beyond the end repeat the last edge
@@ -574,6 +625,18 @@ __global__ __launch_bounds__(kF2Block) void node_kernel_f2(const NodeArgs a, con
     Tile<L> v;  // the tile's node features in accumulator layout (after the update: x')
     int k = 0;
     if (a.do_update) {
+      // in-degrees and reduction slots of the tile's rows (used by the aggregate phase, loaded a phase ahead)
+      int dg[4], tf[4], tl[4];
+      int64_t nd[4];
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int r = it * 8 + (lq >> 3);
+        nd[it] = n0 + (r < rlim ? r : rlim);
+        const int r0 = a.rowptr[nd[it]], r1 = a.rowptr[nd[it] + 1];
+        dg[it] = r1 - r0;
+        tf[it] = r0 >> a.red_shift;
+        tl[it] = dg[it] > 0 && !DBG(2048) ? (r1 - 1) >> a.red_shift : tf[it];
+      }
       Tile<L> acc;
       float scale, inv;
       {
@@ -604,17 +667,6 @@ __global__ __launch_bounds__(kF2Block) void node_kernel_f2(const NodeArgs a, con
         // Three rounds of loads, each issued for all four row pieces of the lane before any is used: rowptr; the row
         // of sums (agg, or the tail slot when tile boundaries of the edge kernel cut the row); the first head slot of
         // a cut row.  Rows cut more than once (longer than a tile) add their further heads in a loop.
-        int dg[4], tf[4], tl[4];
-        int64_t nd[4];
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-          const int r = it * 8 + (lq >> 3);
-          nd[it] = n0 + (r < rlim ? r : rlim);
-          const int r0 = a.rowptr[nd[it]], r1 = a.rowptr[nd[it] + 1];
-          dg[it] = r1 - r0;
-          tf[it] = r0 >> a.red_shift;
-          tl[it] = dg[it] > 0 && !DBG(2048) ? (r1 - 1) >> a.red_shift : tf[it];
-        }
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
           const float* src = tl[it] != tf[it] ? a.tail + static_cast<int64_t>(tf[it]) * L : a.agg + nd[it] * L;
@@ -830,25 +882,27 @@ bool edge_f2_supported(int L, int nl, int act, int residual, int layer_norm) {
          layer_norm != AMBER_MODE_OUTER && edge_f2_lds_bytes(L, nl) <= 160 * 1024;
 }
 
-template <int L>
+template <int L, bool EMB>
 static hipError_t launch_edge_f2_t(const EdgeArgs& a, int num_cus, hipStream_t s) {
   const int64_t ntiles = (a.E + kTile - 1) / kTile;
   if (ntiles == 0) return hipSuccess;
   const size_t lds = edge_f2_lds_bytes(L, a.nl);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(edge_kernel_f2<L>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     static_cast<int>(lds));
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(edge_kernel_f2<L, EMB>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
   if (e != hipSuccess) return e;
   int64_t grid = (num_cus / 8) * 8;  // one persistent workgroup per CU, a multiple of the 8 XCDs
   if (grid < 8) grid = 8;
-  hipLaunchKernelGGL(edge_kernel_f2<L>, dim3(static_cast<unsigned>(grid)), dim3(kF2Block), lds, s, a, ntiles);
+  hipLaunchKernelGGL((edge_kernel_f2<L, EMB>), dim3(static_cast<unsigned>(grid)), dim3(kF2Block), lds, s, a, ntiles);
   return hipGetLastError();
 }
 
 hipError_t launch_edge_f2(int L, const EdgeArgs& a, int num_cus, hipStream_t s) {
+  if (a.E == 0) return hipSuccess;
+  if (a.emb_on && (a.emb_f < 0 || a.emb_f > kMaxFusedEmbed || !a.emb_b || !a.perm)) return hipErrorInvalidValue;
   switch (L) {
-    case 32: return launch_edge_f2_t<32>(a, num_cus, s);
-    case 64: return launch_edge_f2_t<64>(a, num_cus, s);
-    case 128: return launch_edge_f2_t<128>(a, num_cus, s);
+    case 32: return a.emb_on ? launch_edge_f2_t<32, true>(a, num_cus, s) : launch_edge_f2_t<32, false>(a, num_cus, s);
+    case 64: return a.emb_on ? launch_edge_f2_t<64, true>(a, num_cus, s) : launch_edge_f2_t<64, false>(a, num_cus, s);
+    case 128: return a.emb_on ? launch_edge_f2_t<128, true>(a, num_cus, s) : launch_edge_f2_t<128, false>(a, num_cus, s);
     default: return hipErrorInvalidValue;
   }
 }

@@ -46,7 +46,15 @@ struct EdgeArgs {
   int32_t write_e;        // store the updated e (CSR order)
   float* out_edge;        // [E,L] edge_index order, or nullptr
   int32_t dbg;            // experiment switches (AMBER_MPN_DBG), 0 in production
+  // first step with the linear edge embedding fused in (K1): e is not read, its rows are computed on the fly as
+  // emb_b + emb_w * edge_attr[perm[p]]; emb_attr == nullptr: e holds the embedded rows as usual
+  const float* emb_attr;  // [E, emb_f] raw edge features, edge_index order
+  const float* emb_w;     // [L, emb_f]
+  const float* emb_b;     // [L]
+  int32_t emb_f;          // 0 .. kMaxFusedEmbed
+  int32_t emb_on;
 };
+constexpr int kMaxFusedEmbed = 4;
 
 // Arguments of the fused node kernel (K6 finish, K7, K8, next step's first-layer projections, K9, K10).
 struct NodeArgs {
