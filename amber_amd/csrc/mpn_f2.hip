@@ -335,14 +335,12 @@ __global__ __launch_bounds__(kF2Block) void edge_kernel_f2(const EdgeArgs a, con
         const int r = 8 * (i >> 2) + (i & 3) + 4 * h;
         float ev[kMaxFusedEmbed];
 #pragma unroll
-        for (int k = 0; k < kMaxFusedEmbed; ++k)
-          if (k < a.emb_f) ev[k] = __shfl(eav[k], r);  // wave-uniform guard
+        for (int k = 0; k < kMaxFusedEmbed; ++k) ev[k] = __shfl(eav[k], r);
 #pragma unroll
         for (int fb = 0; fb < NFB; ++fb) {
           float v = bq[fb];
 #pragma unroll
-          for (int k = 0; k < kMaxFusedEmbed; ++k)
-            if (k < a.emb_f) v = fmaf(ev[k], wq[fb][k], v);  // k ascending, as the embed kernel
+          for (int k = 0; k < kMaxFusedEmbed; ++k) v = fmaf(ev[k], wq[fb][k], v);  // k ascending, as the embed kernel
           t.a[fb][i] = v;
         }
       }
