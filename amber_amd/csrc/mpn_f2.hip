@@ -71,14 +71,24 @@ DEVINL float tile_absmax(const Tile<L>& t) {
     }
   return fmaxf(m0, m1);
 }
+// x * scale -> hi + lo fp16, four values.  v_fma_mixlo/mixhi_f16 compute the f32 fma and round once to fp16 into one
+// half of the destination: hi = fp16(x * scale), lo = fp16(x * scale - hi) (the difference is exact in f32), two
+// instructions a value.  (Left to the compiler the same arithmetic took about 3.5.)
 DEVINL void split4(const f32x4 x, float scale, half4& hi, half4& lo) {
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  u32x2 hh, ll;
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const float xs = x[t] * scale;
-    const _Float16 hh = static_cast<_Float16>(xs);
-    hi[t] = hh;
-    lo[t] = static_cast<_Float16>(xs - static_cast<float>(hh));
+  for (int p = 0; p < 2; ++p) {
+    unsigned hv, lv;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hv) : "v"(x[2 * p]), "v"(scale));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hv) : "v"(x[2 * p + 1]), "v"(scale));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(lv) : "v"(x[2 * p]), "v"(scale), "v"(hv));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lv) : "v"(x[2 * p + 1]), "v"(scale), "v"(hv));
+    hh[p] = hv;
+    ll[p] = lv;
   }
+  hi = __builtin_bit_cast(half4, hh);
+  lo = __builtin_bit_cast(half4, ll);
 }
 // sum over the 32 lanes of a half-wave, result in every lane of the half
 DEVINL float half_sum(float v) {
