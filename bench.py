@@ -30,7 +30,7 @@ from amber_amd.architecture.supervised_mpn import SupervisedMPN  # noqa: E402
 from amber_amd.config import default_architecture  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-FP32_MFMA_PEAK_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32 dense peak (same guide)
+F16_MFMA_PEAK_TFLOPS = 2500.0  # dense fp16 / bf16 MFMA peak (same guide)
 
 
 def parse():
@@ -152,14 +152,17 @@ def main():
         kernels = {"embed_ms_per_forward": ms[0] / reps, "edge_ms_per_launch": edge_ms, "node_ms_per_launch": node_ms,
                    "edge_launches_per_forward": cnt[1] // reps, "node_launches_per_forward": cnt[2] // reps,
                    "device_ms_per_forward": sum(ms) / reps, "csr_build_ms_once_per_mesh": csr_ms}
-        # Dominant kernel = edge_kernel<L>.  Algorithmic work per launch (stated in DESIGN.md):
-        #   bytes: E * (16 L + 8): read e, gather two node rows, write e', two int32 indices; the last of the S
-        #          launches writes no e' (E * (12 L + 8)), so the average launch moves E * ((16 - 4/S) L + 8) bytes
-        #   flops: E * 4 L^2 in the weight-split form the kernel implements (direct form: E * 8 L^2)
-        bytes_per_launch = e * ((16.0 - 4.0 / S) * L + 8.0)
-        flops_per_launch = e * 4.0 * L * L
-        ach_tf = flops_per_launch / (edge_ms * 1e-3) / 1e12
+        # Dominant kernel = edge_kernel_f2<L> (split-precision fp16x2 MFMA chain, fp32-grade).  Per launch
+        # (stated in DESIGN.md):
+        #   algorithmic bytes: E * (16 L + 8): read e, gather two node rows, write e', two int32 indices
+        #   (the first launch computes e from the raw edge features and the last writes no e': 4 L E fewer bytes each)
+        #   matrix work: E * 4 L^2 useful flops in the weight-split form (direct form E * 8 L^2); every product is
+        #   carried out as three fp16 MFMAs, so the matrix pipe executes 3x that
+        # With fp16 matrix rates the MFMA floor of a launch (~0.8 ms) lies below its HBM floor (2.5 ms): HBM binds.
+        bytes_per_launch = e * (16.0 * L + 8.0)
+        flops_useful = e * 4.0 * L * L
         ach_gbs = bytes_per_launch / (edge_ms * 1e-3) / 1e9
+        ach_tf_exec = 3.0 * flops_useful / (edge_ms * 1e-3) / 1e12
         traffic = None
         tpath = os.path.join(REPO, "profiles", "traffic.json")
         if os.path.exists(tpath):
@@ -167,11 +170,12 @@ def main():
                 traffic = json.load(open(tpath)).get("edge_kernel_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        roofline = {"kernel": f"edge_kernel<{L}>", "bound": "mfma", "achieved": ach_tf, "peak": FP32_MFMA_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": ach_tf / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                    "flops_form": "weight-split E*4L^2 (direct form E*8L^2 = 2x)", "avg_launch_ms": edge_ms}
-        roofline_hbm = {"kernel": f"edge_kernel<{L}>", "bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": ach_gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": bytes_per_launch}
+        roofline = {"kernel": f"edge_kernel_f2<{L}>", "bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": bytes_per_launch,
+                    "avg_launch_ms": edge_ms}
+        roofline_hbm = {"kernel": f"edge_kernel_f2<{L}>", "bound": "mfma", "achieved": ach_tf_exec, "peak": F16_MFMA_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": ach_tf_exec / F16_MFMA_PEAK_TFLOPS,
+                        "note": "executed fp16 MFMA flops = 3 x useful E*4L^2 (hi*hi, hi*lo, lo*hi); not the binding roof"}
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(cfg, state_dict, args)
 
@@ -182,14 +186,14 @@ def main():
         line = {
             "metric": "mpn_forward_edges_per_sec", "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": t / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32", "precision": engine.default_precision, "data": "synthetic",
             "config": {"workload": f"BASELINE config 5: disjoint batch of {args.graphs} triangulated {args.nx}x{args.ny} grids per "
                                    f"{'GPU' if args.scaling == 'weak' else 'job'}, N={n} E={e} on rank 0, F_n=4 F_e=2, latent {args.latent}, "
                                    f"{args.mp_steps} MP steps, inner residual + inner LayerNorm, leakyrelu, decoder + readout",
                        "global_edges_per_step": total_edges / args.steps, "parallelism": f"graph-wise dp{world}, no collective"},
             "edge_steps_per_sec": value * args.mp_steps,
             "hbm_roofline_frac_whole_forward": (bytes_fwd / (t / args.steps)) / (HBM_PEAK_GBS * 1e9) if world == 1 else None,
-            "roofline": roofline, "roofline_hbm": roofline_hbm, "kernels": kernels, "cpu_baseline": cpu,
+            "roofline": roofline, "roofline_mfma": roofline_hbm, "kernels": kernels, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
     if dist is not None:
