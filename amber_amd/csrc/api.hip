@@ -518,14 +518,12 @@ int amber_mpn_pack_weights(const AmberMpnDesc* desc, const float* params, float*
   const Layout lay = build_layout(*desc);
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int L = desc->latent;
-  // Per matrix the operand format follows its consumer: FMT_F32 = exact fp32 tiles; FMT_H = hi/lo fp16 (f16x2) as
-  // the A operand of the row-per-lane chain (fast node kernel: node MLP, next-step W0s / W0d); FMT_F2 = hi/lo fp16 as
-  // the B operand of the feature-per-lane chain (edge kernel: W0e and later edge layers).  `f0[cb]` is the format
-  // of column block cb of layer 0, `share0` makes its FMT_H blocks share one power-of-two scale (they feed one
-  // accumulator), `frest` is the format of layers >= 1.
-  enum { FMT_F32 = 0, FMT_H = 1, FMT_F2 = 2 };
+  // Per matrix the operand format follows its consumer: FMT_F32 = exact fp32 tiles (A operand of the row-per-lane
+  // chain: exact kernels, decoder); FMT_F2 = hi/lo fp16 as the B operand of the feature-per-lane chain (split-precision
+  // edge and node kernels).  `f0[cb]` is the format of column block cb of layer 0, `share0` makes its FMT_F2 blocks
+  // share one power-of-two scale (they feed one accumulator), `frest` is the format of layers >= 1.
+  enum { FMT_F32 = 0, FMT_F2 = 2 };
   auto pack_one = [&](int fmt, const float* W, int ld, int col0, int scol0, int scols, float* out) -> hipError_t {
-    if (fmt == FMT_H) return launch_pack_h(L, W, ld, col0, scol0, scols, out, s);
     if (fmt == FMT_F2) return launch_pack_f2(L, W, ld, col0, scol0, scols, out, s);
     return launch_pack(L, W, ld, col0, out, s);
   };

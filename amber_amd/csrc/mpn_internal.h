@@ -68,7 +68,7 @@ struct NodeArgs {
   const float* head;
   const float* tail;
   int32_t red_shift;      // log2 of the reduction tile of head / tail (must match the edge kernel that wrote them)
-  int32_t fast;           // update / projection weights are in the split-precision (f16x2) operand format
+  int32_t fast;           // update / projection weights are in the split-precision B-operand format (node_kernel_f2)
   const float* w0x;       // packed W0[:, 0:L]
   const float* w0a;       // packed W0[:, L:2L]
   const float* b0;
@@ -109,11 +109,8 @@ hipError_t launch_embed(int L, const float* in, int64_t rows, int F, const float
                         int act_or_neg1, float* out, hipStream_t s);
 // re-tile W[L, ld] columns [col0, col0+L) into MFMA operand order
 hipError_t launch_pack(int L, const float* W, int ld, int col0, float* out, hipStream_t s);
-// split-precision (f16x2) path, mpn_fast.hip.  A packed matrix is L*L floats of body + kPackedHeader floats.
+// A packed matrix is L*L floats of body + kPackedHeader floats (split-precision formats keep their scales there).
 constexpr int kPackedHeader = 8;
-// scale_col0 / scale_cols: the column range of W whose max |w| fixes the power-of-two scale (matrices that feed one
-// accumulator, such as the two halves of the node MLP's first layer, must share it)
-hipError_t launch_pack_h(int L, const float* W, int ld, int col0, int scale_col0, int scale_cols, float* out, hipStream_t s);
 // feature-per-lane split-precision edge kernel, mpn_f2.hip (weights as B operand: launch_pack_f2)
 hipError_t launch_pack_f2(int L, const float* W, int ld, int col0, int scale_col0, int scale_cols, float* out, hipStream_t s);
 hipError_t launch_edge_f2(int L, const EdgeArgs& a, int num_cus, hipStream_t s);

@@ -124,9 +124,7 @@ __global__ __launch_bounds__(kBlock) void edge_kernel(const EdgeArgs a, const in
 //            SupervisedMPN.forward (src/algorithm/architecture/supervised_mpn.py:51-54), MLP (mlp.py:60-95)
 // Also used as a generic row-wise dense chain (embedding MLP tail).
 // ---------------------------------------------------------------------------------------------------
-// FAST = split-precision (f16x2) contractions for the update and projection phases (packed weights in the hi/lo
-// fp16 operand format, read from L2 as coalesced 1 KB fragments); the dense chain (decoder) stays exact.
-template <int L, bool FAST>
+template <int L>
 __global__ __launch_bounds__(kBlock) void node_kernel(const NodeArgs a, const int64_t nblk) {
   __shared__ __attribute__((aligned(16))) float stage_all[kWavesPerBlock * stage_floats<L>()];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -165,41 +163,16 @@ __global__ __launch_bounds__(kBlock) void node_kernel(const NodeArgs a, const in
     }
     Tile<L> acc;
     tile_load_vec<L>(acc, a.b0, h);
-    if constexpr (FAST) {
-      // one power-of-two scale for both operands of the first layer (x and the aggregate share the accumulator)
-      float sv, iv, sg, ig;
-      tile_row_scale<L>(v, sv, iv);
-      tile_row_scale<L>(g, sg, ig);
-      const float scale = fminf(sv, sg), inv = fmaxf(iv, ig);
-      tile_scale<L>(acc, scale * a.w0x[L * L + 1]);
-      tile_gemm_h<L>(acc, reinterpret_cast<const unsigned char*>(a.w0x), v, scale, lane);
-      tile_gemm_h<L>(acc, reinterpret_cast<const unsigned char*>(a.w0a), g, scale, lane);
-      tile_scale<L>(acc, inv * a.w0x[L * L]);
-      tile_act_fast<L>(acc, a.act);
+    tile_gemm<L>(acc, a.w0x, v, lane);
+    tile_gemm<L>(acc, a.w0a, g, lane);
+    tile_act<L>(acc, a.act, stage, lane);
 #pragma unroll 1
-      for (int l = 1; l < a.nl; ++l) {
-        Tile<L> nxt;
-        float sc, in_;
-        tile_row_scale<L>(acc, sc, in_);
-        tile_load_vec<L>(nxt, a.layers[l].b, h);
-        tile_scale<L>(nxt, sc * a.layers[l].w[L * L + 1]);
-        tile_gemm_h<L>(nxt, reinterpret_cast<const unsigned char*>(a.layers[l].w), acc, sc, lane);
-        tile_scale<L>(nxt, in_ * a.layers[l].w[L * L]);
-        tile_act_fast<L>(nxt, a.act);
-        acc = nxt;
-      }
-    } else {
-      tile_gemm<L>(acc, a.w0x, v, lane);
-      tile_gemm<L>(acc, a.w0a, g, lane);
-      tile_act<L>(acc, a.act, stage, lane);
-#pragma unroll 1
-      for (int l = 1; l < a.nl; ++l) {
-        Tile<L> nxt;
-        tile_load_vec<L>(nxt, a.layers[l].b, h);
-        tile_gemm<L>(nxt, a.layers[l].w, acc, lane);
-        tile_act<L>(nxt, a.act, stage, lane);
-        acc = nxt;
-      }
+    for (int l = 1; l < a.nl; ++l) {
+      Tile<L> nxt;
+      tile_load_vec<L>(nxt, a.layers[l].b, h);
+      tile_gemm<L>(nxt, a.layers[l].w, acc, lane);
+      tile_act<L>(nxt, a.act, stage, lane);
+      acc = nxt;
     }
     // order of message_passing_block.py:124-128: inner residual, inner LN, outer residual, outer LN
     if (a.residual == AMBER_MODE_INNER) tile_add<L>(acc, v);
@@ -216,28 +189,14 @@ __global__ __launch_bounds__(kBlock) void node_kernel(const NodeArgs a, const in
   }
   if (a.do_proj) {
     Tile<L> acc;
-    float sc = 1.f, in_ = 1.f;
-    if constexpr (FAST) {
-      tile_row_scale<L>(v, sc, in_);
-      tile_zero<L>(acc);
-      tile_gemm_h<L>(acc, reinterpret_cast<const unsigned char*>(a.w0s), v, sc, lane);
-      tile_scale<L>(acc, in_ * a.w0s[L * L]);
-    } else {
-      tile_zero<L>(acc);
-      tile_gemm<L>(acc, a.w0s, v, lane);
-    }
+    tile_zero<L>(acc);
+    tile_gemm<L>(acc, a.w0s, v, lane);
     __syncthreads();
     tile_stage<L>(stage, acc, c, h);
     __syncthreads();
     stage_store_rows<L>(stage, a.Ps, n0, nvalid, nullptr, lane);
     tile_load_vec<L>(acc, a.b0e, h);
-    if constexpr (FAST) {
-      tile_scale<L>(acc, sc * a.w0d[L * L + 1]);
-      tile_gemm_h<L>(acc, reinterpret_cast<const unsigned char*>(a.w0d), v, sc, lane);
-      tile_scale<L>(acc, in_ * a.w0d[L * L]);
-    } else {
-      tile_gemm<L>(acc, a.w0d, v, lane);
-    }
+    tile_gemm<L>(acc, a.w0d, v, lane);
     __syncthreads();
     tile_stage<L>(stage, acc, c, h);
     __syncthreads();
@@ -386,10 +345,7 @@ template <int L>
 static hipError_t launch_node_t(const NodeArgs& a, hipStream_t s) {
   const int64_t nblk = cdiv(cdiv(a.N, kTile), kWavesPerBlock);
   if (nblk == 0) return hipSuccess;
-  if (a.fast)
-    hipLaunchKernelGGL((node_kernel<L, true>), dim3(static_cast<unsigned>(nblk)), dim3(kBlock), 0, s, a, nblk);
-  else
-    hipLaunchKernelGGL((node_kernel<L, false>), dim3(static_cast<unsigned>(nblk)), dim3(kBlock), 0, s, a, nblk);
+  hipLaunchKernelGGL(node_kernel<L>, dim3(static_cast<unsigned>(nblk)), dim3(kBlock), 0, s, a, nblk);
   return hipGetLastError();
 }
 template <int L>

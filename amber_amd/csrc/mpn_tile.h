@@ -243,7 +243,7 @@ DEVINL int64_t xcd_remap(int64_t bid, int64_t nblk) {
 }
 
 
-// ---- split-precision (f16x2) helpers, see the note at the top of mpn_fast.hip ----
+// ---- split-precision (f16x2) helpers, see the note at the top of mpn_f2.hip ----
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
 DEVINL void wave_sync() {
@@ -255,56 +255,6 @@ DEVINL void wave_sync() {
 }
 
 constexpr int kMinScaleExp = 127 - 24;
-
-// power-of-two scale that brings max|row| into [2^14, 2^15), and its inverse
-template <int L>
-DEVINL void tile_row_scale(const Tile<L>& t, float& scale, float& inv) {
-  float m0 = 0.f, m1 = 0.f;
-#pragma unroll
-  for (int fb = 0; fb < L / 32; ++fb)
-#pragma unroll
-    for (int i = 0; i < 16; i += 2) {
-      m0 = fmaxf(m0, fabsf(t.a[fb][i]));
-      m1 = fmaxf(m1, fabsf(t.a[fb][i + 1]));
-    }
-  float m = fmaxf(m0, m1);
-  m = fmaxf(m, __shfl_xor(m, 32));
-  int ex = static_cast<int>((__float_as_uint(m) >> 23) & 0xffu);
-  ex = ex < kMinScaleExp ? kMinScaleExp : ex;  // rows below 2^-24 keep a bounded scale (no overflow of scaled biases)
-  scale = __uint_as_float(static_cast<unsigned>(268 - ex) << 23);
-  inv = __uint_as_float(static_cast<unsigned>(ex - 14) << 23);
-}
-
-// acc += (W * scale_w) * (in * scale), W pre-split and pre-tiled in LDS: [k-step s][fb][hi|lo][lane] x 16 B
-template <int L>
-DEVINL void tile_gemm_h(Tile<L>& acc, const unsigned char* wl, const Tile<L>& in, float scale, int lane) {
-  constexpr int NFB = L / 32, NS = L / 16;
-  const half8* w = reinterpret_cast<const half8*>(wl) + lane;
-#pragma unroll
-  for (int s = 0; s < NS; ++s) {
-    half8 bh, bl;
-#pragma unroll
-    for (int jj = 0; jj < 8; ++jj) {
-      const int j = 2 * s + (jj >> 2), t = jj & 3;
-      const float xs = in.a[j >> 2][(j & 3) * 4 + t] * scale;
-      const _Float16 hi = static_cast<_Float16>(xs);
-      bh[jj] = hi;
-      bl[jj] = static_cast<_Float16>(xs - static_cast<float>(hi));
-    }
-    half8 ah[NFB], al[NFB];
-#pragma unroll
-    for (int fb = 0; fb < NFB; ++fb) {
-      ah[fb] = w[((s * NFB + fb) * 2 + 0) * 64];
-      al[fb] = w[((s * NFB + fb) * 2 + 1) * 64];
-    }
-#pragma unroll
-    for (int fb = 0; fb < NFB; ++fb) acc.a[fb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[fb], bh, acc.a[fb], 0, 0, 0);
-#pragma unroll
-    for (int fb = 0; fb < NFB; ++fb) acc.a[fb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[fb], bl, acc.a[fb], 0, 0, 0);
-#pragma unroll
-    for (int fb = 0; fb < NFB; ++fb) acc.a[fb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[fb], bh, acc.a[fb], 0, 0, 0);
-  }
-}
 
 // t *= factor (a power of two: exact)
 template <int L>
