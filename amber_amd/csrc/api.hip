@@ -77,7 +77,7 @@ int validate(const AmberMpnDesc* d) {
       return fail(AMBER_ERR_UNSUPPORTED, "decoder activation id %d", d->decoder_activation);
     if (d->decoder_norm < 0 || d->decoder_norm > 2) return fail(AMBER_ERR_INVALID_ARGUMENT, "bad decoder_norm");
   }
-  if (d->precision != AMBER_PREC_FP32 && d->precision != AMBER_PREC_F16X2)
+  if (d->precision != AMBER_PREC_FP32 && d->precision != AMBER_PREC_F16X2 && d->precision != AMBER_PREC_F16)
     return fail(AMBER_ERR_UNSUPPORTED, "precision id %d", d->precision);
   if (!(d->ln_eps > 0.f)) return fail(AMBER_ERR_INVALID_ARGUMENT, "ln_eps must be > 0");
   return AMBER_OK;
@@ -240,10 +240,10 @@ struct Timer {
 };
 
 bool use_fast_edge(const AmberMpnDesc& d) {
-  return d.precision == AMBER_PREC_F16X2 && edge_f2_supported(d.latent, d.mlp_layers, d.activation, d.residual, d.layer_norm);
+  return d.precision != AMBER_PREC_FP32 && edge_f2_supported(d.latent, d.mlp_layers, d.activation, d.residual, d.layer_norm);
 }
 bool use_fast_node(const AmberMpnDesc& d) {
-  return d.precision == AMBER_PREC_F16X2 && node_f2_supported(d.latent, d.activation, d.residual, d.layer_norm);
+  return d.precision != AMBER_PREC_FP32 && node_f2_supported(d.latent, d.activation, d.residual, d.layer_norm);
 }
 int device_cus() {
   int dev = 0, cus = 0;
@@ -254,6 +254,7 @@ int device_cus() {
 hipError_t run_edge(const AmberMpnDesc& d, EdgeArgs& ea, hipStream_t s) {
   if (use_fast_edge(d)) {
     ea.red_shift = 5;
+    ea.single = d.precision == AMBER_PREC_F16 ? 1 : 0;
     return launch_edge_f2(d.latent, ea, device_cus(), s);
   }
   ea.red_shift = 5;
@@ -267,6 +268,7 @@ hipError_t run_node(const AmberMpnDesc& d, const NodeArgs& na, hipStream_t s) {
   NodeArgs u = na;
   const char* dbg = getenv("AMBER_MPN_DBG");
   u.dbg = dbg ? atoi(dbg) : 0;
+  u.single = d.precision == AMBER_PREC_F16 ? 1 : 0;
   u.n_dense = 0;
   u.do_readout = 0;
   u.dense_out = nullptr;

@@ -90,6 +90,19 @@ DEVINL void split4(const f32x4 x, float scale, half4& hi, half4& lo) {
   hi = __builtin_bit_cast(half4, hh);
   lo = __builtin_bit_cast(half4, ll);
 }
+// single-term variant (AMBER_PREC_F16): x * scale -> fp16, no correction term
+DEVINL void round4(const f32x4 x, float scale, half4& hi) {
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  u32x2 hh;
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    unsigned hv;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hv) : "v"(x[2 * p]), "v"(scale));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hv) : "v"(x[2 * p + 1]), "v"(scale));
+    hh[p] = hv;
+  }
+  hi = __builtin_bit_cast(half4, hh);
+}
 // sum over the 32 lanes of a half-wave, result in every lane of the half
 DEVINL float half_sum(float v) {
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
@@ -115,7 +128,8 @@ struct ELanding {
 
 // one 16-deep k-step of all feature blocks: acc[fb] += A(hi, lo) x W^T(hi, lo), weights in LDS as
 // [k-step s][fb][hi | lo][lane] x 16 bytes
-template <int L>
+// SPLIT = false (AMBER_PREC_F16): plain fp16 operands, the hi terms only - one MFMA a product (tolerance 1e-2)
+template <int L, bool SPLIT>
 DEVINL void kstep(Tile<L>& acc, const half8 ah, const half8 al, const unsigned char* wl, int s, int lane) {
   constexpr int NFB = L / 32;
   const half8* w = reinterpret_cast<const half8*>(wl) + lane;
@@ -123,16 +137,17 @@ DEVINL void kstep(Tile<L>& acc, const half8 ah, const half8 al, const unsigned c
 #pragma unroll
   for (int fb = 0; fb < NFB; ++fb) {
     bh[fb] = w[((s * NFB + fb) * 2 + 0) * 64];
-    bl[fb] = w[((s * NFB + fb) * 2 + 1) * 64];
+    if constexpr (SPLIT) bl[fb] = w[((s * NFB + fb) * 2 + 1) * 64];
   }
 #pragma unroll
   for (int fb = 0; fb < NFB; ++fb) acc.a[fb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[fb], acc.a[fb], 0, 0, 0);
+  if constexpr (SPLIT) {
 #pragma unroll
-  for (int fb = 0; fb < NFB; ++fb) acc.a[fb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[fb], acc.a[fb], 0, 0, 0);
+    for (int fb = 0; fb < NFB; ++fb) acc.a[fb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[fb], acc.a[fb], 0, 0, 0);
 #pragma unroll
-  for (int fb = 0; fb < NFB; ++fb) acc.a[fb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[fb], acc.a[fb], 0, 0, 0);
+    for (int fb = 0; fb < NFB; ++fb) acc.a[fb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[fb], acc.a[fb], 0, 0, 0);
+  }
 }
-
 
 // lane-constant byte offsets into the wave's LDS window
 struct WinOff {
@@ -168,7 +183,7 @@ DEVINL WinOff make_win_off(int lane) {
 
 // acc += (tile * scale) x W^T for a tile held as whole row pieces (ELanding): 32 features a pass are split into hi/lo
 // fp16, written to the window as a [row][feature] image and read back as the A operand with ds_read_b128
-template <int L>
+template <int L, bool SPLIT>
 DEVINL void gemm_rows(Tile<L>& acc, const ELanding<L>& la, float scale, unsigned char* win, const WinOff& o,
                       const unsigned char* wl, int lane) {
 #pragma unroll
@@ -177,23 +192,28 @@ DEVINL void gemm_rows(Tile<L>& acc, const ELanding<L>& la, float scale, unsigned
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       half4 hi, lo;
-      split4(la.v[ps][it], scale, hi, lo);
+      if constexpr (SPLIT) {
+        split4(la.v[ps][it], scale, hi, lo);
+        *reinterpret_cast<half4*>(win + kLoPlane + o.ew[it]) = lo;
+      } else {
+        round4(la.v[ps][it], scale, hi);
+      }
       *reinterpret_cast<half4*>(win + o.ew[it]) = hi;
-      *reinterpret_cast<half4*>(win + kLoPlane + o.ew[it]) = lo;
     }
     wave_sync();
 #pragma unroll
     for (int sp = 0; sp < 2; ++sp) {
       const half8 ah = *reinterpret_cast<const half8*>(win + o.er[sp]);
-      const half8 al = *reinterpret_cast<const half8*>(win + kLoPlane + o.er[sp]);
-      kstep<L>(acc, ah, al, wl, 2 * ps + sp, lane);
+      half8 al = ah;
+      if constexpr (SPLIT) al = *reinterpret_cast<const half8*>(win + kLoPlane + o.er[sp]);
+      kstep<L, SPLIT>(acc, ah, al, wl, 2 * ps + sp, lane);
     }
   }
 }
 
 // acc += (tile * scale) x W^T for a tile in accumulator layout (feature per lane): 32 features a pass go through the
 // window as a [feature][row] image and come back as the A operand through the transposing read
-template <int L>
+template <int L, bool SPLIT>
 DEVINL void gemm_acc(Tile<L>& acc, const Tile<L>& in, float scale, unsigned char* win, const WinOff& o,
                      const unsigned char* wl, int lane) {
 #pragma unroll
@@ -207,24 +227,34 @@ DEVINL void gemm_acc(Tile<L>& acc, const Tile<L>& in, float scale, unsigned char
       x[2] = in.a[fb][4 * g + 2];
       x[3] = in.a[fb][4 * g + 3];
       half4 hi, lo;
-      split4(x, scale, hi, lo);
+      if constexpr (SPLIT) {
+        split4(x, scale, hi, lo);
+        *reinterpret_cast<half4*>(win + kLoPlane + o.hw[g]) = lo;
+      } else {
+        round4(x, scale, hi);
+      }
       *reinterpret_cast<half4*>(win + o.hw[g]) = hi;
-      *reinterpret_cast<half4*>(win + kLoPlane + o.hw[g]) = lo;
     }
     wave_sync();
 #pragma unroll
     for (int sp = 0; sp < 2; ++sp) {
       const half4 a0 = lds_read_tr(win + o.hr[sp][0]), a1 = lds_read_tr(win + o.hr[sp][1]);
-      const half4 b0 = lds_read_tr(win + kLoPlane + o.hr[sp][0]), b1 = lds_read_tr(win + kLoPlane + o.hr[sp][1]);
       half8 ah, al;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         ah[t] = a0[t];
         ah[4 + t] = a1[t];
-        al[t] = b0[t];
-        al[4 + t] = b1[t];
       }
-      kstep<L>(acc, ah, al, wl, 2 * fb + sp, lane);
+      al = ah;
+      if constexpr (SPLIT) {
+        const half4 b0 = lds_read_tr(win + kLoPlane + o.hr[sp][0]), b1 = lds_read_tr(win + kLoPlane + o.hr[sp][1]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          al[t] = b0[t];
+          al[4 + t] = b1[t];
+        }
+      }
+      kstep<L, SPLIT>(acc, ah, al, wl, 2 * fb + sp, lane);
     }
   }
 }
@@ -270,7 +300,7 @@ DEVINL void tile_layernorm_acc(Tile<L>& acc, const float* __restrict__ gamma, co
 }
 
 // EMB: first step with the linear edge embedding fused in (e is computed on the fly instead of read)
-template <int L, bool EMB>
+template <int L, bool EMB, bool SPLIT>
 __global__ __launch_bounds__(kF2Block) void edge_kernel_f2(const EdgeArgs a, const int64_t ntiles) {
   constexpr int NFB = L / 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -393,11 +423,11 @@ __global__ __launch_bounds__(kF2Block) void edge_kernel_f2(const EdgeArgs a, con
       embed_tile(e0);
       pow2_scale(wave_max(tile_absmax<L>(e0)), scale, inv);
       tile_scale<L>(acc, scale * wscale0);
-      gemm_acc<L>(acc, e0, scale, win, wo, smem, lane);
+      gemm_acc<L, SPLIT>(acc, e0, scale, win, wo, smem, lane);
     } else {
       pow2_scale(wave_max(landing_absmax<L>(la)), scale, inv);
       tile_scale<L>(acc, scale * wscale0);
-      if (!DBG(8)) gemm_rows<L>(acc, la, scale, win, wo, smem, lane);
+      if (!DBG(8)) gemm_rows<L, SPLIT>(acc, la, scale, win, wo, smem, lane);
     }
     // destination terms (rows repeat inside a tile: L1 / L2 hits) join after the contraction, when the landing
     // registers of e are free again
@@ -427,7 +457,7 @@ __global__ __launch_bounds__(kF2Block) void edge_kernel_f2(const EdgeArgs a, con
           for (int i = 0; i < 16; ++i) nxt.a[fb][i] = b;
         }
       }
-      if (!DBG(8)) gemm_acc<L>(nxt, acc, scale, win, wo, smem + l * MAT_BYTES, lane);
+      if (!DBG(8)) gemm_acc<L, SPLIT>(nxt, acc, scale, win, wo, smem + l * MAT_BYTES, lane);
       tile_scale<L>(nxt, inv * wg[L * L]);
       tile_act_fast<L>(nxt, a.act);
       acc = nxt;
@@ -548,7 +578,7 @@ __global__ __launch_bounds__(kF2Block) void edge_kernel_f2(const EdgeArgs a, con
 // matrix streams into the other slot by LDS-DMA (global_load_lds), and one workgroup barrier separates the phases.
 // When all matrices fit (L <= 64) they are loaded once and the phases run without barriers.
 // ---------------------------------------------------------------------------------------------------
-template <int L>
+template <int L, bool SPLIT>
 __global__ __launch_bounds__(kF2Block) void node_kernel_f2(const NodeArgs a, const int64_t ntiles, const int resident) {
   constexpr int NFB = L / 32;
   constexpr int MAT_BYTES = L * L * 4;
@@ -667,7 +697,7 @@ __global__ __launch_bounds__(kF2Block) void node_kernel_f2(const NodeArgs a, con
           for (int i = 0; i < 16; ++i) acc.a[fb][i] = bv;
         }
         const unsigned char* wl = begin_phase(k++);
-        if (!DBG(256)) gemm_rows<L>(acc, lx, scale, win, wo, wl, lane);
+        if (!DBG(256)) gemm_rows<L, SPLIT>(acc, lx, scale, win, wo, wl, lane);
       }
       {
         // ---- whole row pieces of the aggregate: sums of the edge kernel -> mean ----
@@ -719,7 +749,7 @@ __global__ __launch_bounds__(kF2Block) void node_kernel_f2(const NodeArgs a, con
         pow2_scale(wave_max(landing_absmax<L>(lg)), sg, ig);
         tile_scale<L>(acc, sg * inv);
         const unsigned char* wl = begin_phase(k++);
-        if (!DBG(256)) gemm_rows<L>(acc, lg, sg, win, wo, wl, lane);
+        if (!DBG(256)) gemm_rows<L, SPLIT>(acc, lg, sg, win, wo, wl, lane);
         tile_scale<L>(acc, ig * a.w0x[L * L]);
         tile_act_fast<L>(acc, a.act);
       }
@@ -736,7 +766,7 @@ __global__ __launch_bounds__(kF2Block) void node_kernel_f2(const NodeArgs a, con
 #pragma unroll
           for (int i = 0; i < 16; ++i) nxt.a[fb][i] = bv;
         }
-        if (!DBG(256)) gemm_acc<L>(nxt, acc, scale, win, wo, wl, lane);
+        if (!DBG(256)) gemm_acc<L, SPLIT>(nxt, acc, scale, win, wo, wl, lane);
         tile_scale<L>(nxt, inv * wg[L * L]);
         tile_act_fast<L>(nxt, a.act);
         acc = nxt;
@@ -789,7 +819,7 @@ __global__ __launch_bounds__(kF2Block) void node_kernel_f2(const NodeArgs a, con
         const unsigned char* wl = begin_phase(k++);
         Tile<L> acc;
         tile_zero<L>(acc);
-        if (!DBG(256)) gemm_acc<L>(acc, v, scale, win, wo, wl, lane);
+        if (!DBG(256)) gemm_acc<L, SPLIT>(acc, v, scale, win, wo, wl, lane);
         tile_scale<L>(acc, inv * a.w0s[L * L]);
         store_tile(a.Ps, acc);
       }
@@ -814,7 +844,7 @@ __global__ __launch_bounds__(kF2Block) void node_kernel_f2(const NodeArgs a, con
 #pragma unroll
           for (int i = 0; i < 16; ++i) acc.a[fb][i] = bv;
         }
-        if (!DBG(256)) gemm_acc<L>(acc, v, scale, win, wo, wl, lane);
+        if (!DBG(256)) gemm_acc<L, SPLIT>(acc, v, scale, win, wo, wl, lane);
         tile_scale<L>(acc, inv * a.w0d[L * L]);
         store_tile(a.Pd, acc);
       }
@@ -890,27 +920,32 @@ bool edge_f2_supported(int L, int nl, int act, int residual, int layer_norm) {
          layer_norm != AMBER_MODE_OUTER && edge_f2_lds_bytes(L, nl) <= 160 * 1024;
 }
 
-template <int L, bool EMB>
+template <int L, bool EMB, bool SPLIT>
 static hipError_t launch_edge_f2_t(const EdgeArgs& a, int num_cus, hipStream_t s) {
   const int64_t ntiles = (a.E + kTile - 1) / kTile;
   if (ntiles == 0) return hipSuccess;
   const size_t lds = edge_f2_lds_bytes(L, a.nl);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(edge_kernel_f2<L, EMB>),
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(edge_kernel_f2<L, EMB, SPLIT>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
   if (e != hipSuccess) return e;
   int64_t grid = (num_cus / 8) * 8;  // one persistent workgroup per CU, a multiple of the 8 XCDs
   if (grid < 8) grid = 8;
-  hipLaunchKernelGGL((edge_kernel_f2<L, EMB>), dim3(static_cast<unsigned>(grid)), dim3(kF2Block), lds, s, a, ntiles);
+  hipLaunchKernelGGL((edge_kernel_f2<L, EMB, SPLIT>), dim3(static_cast<unsigned>(grid)), dim3(kF2Block), lds, s, a, ntiles);
   return hipGetLastError();
+}
+template <int L>
+static hipError_t launch_edge_f2_l(const EdgeArgs& a, int num_cus, hipStream_t s) {
+  if (a.single) return a.emb_on ? launch_edge_f2_t<L, true, false>(a, num_cus, s) : launch_edge_f2_t<L, false, false>(a, num_cus, s);
+  return a.emb_on ? launch_edge_f2_t<L, true, true>(a, num_cus, s) : launch_edge_f2_t<L, false, true>(a, num_cus, s);
 }
 
 hipError_t launch_edge_f2(int L, const EdgeArgs& a, int num_cus, hipStream_t s) {
   if (a.E == 0) return hipSuccess;
   if (a.emb_on && (a.emb_f < 0 || a.emb_f > kMaxFusedEmbed || !a.emb_b || !a.perm)) return hipErrorInvalidValue;
   switch (L) {
-    case 32: return a.emb_on ? launch_edge_f2_t<32, true>(a, num_cus, s) : launch_edge_f2_t<32, false>(a, num_cus, s);
-    case 64: return a.emb_on ? launch_edge_f2_t<64, true>(a, num_cus, s) : launch_edge_f2_t<64, false>(a, num_cus, s);
-    case 128: return a.emb_on ? launch_edge_f2_t<128, true>(a, num_cus, s) : launch_edge_f2_t<128, false>(a, num_cus, s);
+    case 32: return launch_edge_f2_l<32>(a, num_cus, s);
+    case 64: return launch_edge_f2_l<64>(a, num_cus, s);
+    case 128: return launch_edge_f2_l<128>(a, num_cus, s);
     default: return hipErrorInvalidValue;
   }
 }
@@ -919,7 +954,7 @@ bool node_f2_supported(int L, int act, int residual, int layer_norm) {
   return (act == AMBER_ACT_RELU || act == AMBER_ACT_LEAKYRELU) && residual != AMBER_MODE_OUTER && layer_norm != AMBER_MODE_OUTER;
 }
 
-template <int L>
+template <int L, bool SPLIT>
 static hipError_t launch_node_f2_t(const NodeArgs& a, int num_cus, hipStream_t s) {
   const int64_t ntiles = (a.N + kTile - 1) / kTile;
   if (ntiles == 0 || (!a.do_update && !a.do_proj)) return hipSuccess;
@@ -927,20 +962,20 @@ static hipError_t launch_node_f2_t(const NodeArgs& a, int num_cus, hipStream_t s
   const size_t mat = static_cast<size_t>(L) * L * 4, wins = static_cast<size_t>(kF2Waves) * kWinBytes;
   const int resident = P * mat + wins <= 160 * 1024 ? 1 : 0;
   const size_t lds = (resident ? P : 2) * mat + wins;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(node_kernel_f2<L>), hipFuncAttributeMaxDynamicSharedMemorySize,
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(node_kernel_f2<L, SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      static_cast<int>(lds));
   if (e != hipSuccess) return e;
   int64_t grid = (num_cus / 8) * 8;  // one persistent workgroup per CU, a multiple of the 8 XCDs
   if (grid < 8) grid = 8;
-  hipLaunchKernelGGL(node_kernel_f2<L>, dim3(static_cast<unsigned>(grid)), dim3(kF2Block), lds, s, a, ntiles, resident);
+  hipLaunchKernelGGL((node_kernel_f2<L, SPLIT>), dim3(static_cast<unsigned>(grid)), dim3(kF2Block), lds, s, a, ntiles, resident);
   return hipGetLastError();
 }
 
 hipError_t launch_node_f2(int L, const NodeArgs& a, int num_cus, hipStream_t s) {
   switch (L) {
-    case 32: return launch_node_f2_t<32>(a, num_cus, s);
-    case 64: return launch_node_f2_t<64>(a, num_cus, s);
-    case 128: return launch_node_f2_t<128>(a, num_cus, s);
+    case 32: return a.single ? launch_node_f2_t<32, false>(a, num_cus, s) : launch_node_f2_t<32, true>(a, num_cus, s);
+    case 64: return a.single ? launch_node_f2_t<64, false>(a, num_cus, s) : launch_node_f2_t<64, true>(a, num_cus, s);
+    case 128: return a.single ? launch_node_f2_t<128, false>(a, num_cus, s) : launch_node_f2_t<128, true>(a, num_cus, s);
     default: return hipErrorInvalidValue;
   }
 }

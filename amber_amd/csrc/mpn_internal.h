@@ -53,6 +53,7 @@ struct EdgeArgs {
   const float* emb_b;     // [L]
   int32_t emb_f;          // 0 .. kMaxFusedEmbed
   int32_t emb_on;
+  int32_t single;         // AMBER_PREC_F16: plain fp16 operands (one MFMA a product) instead of the hi/lo split
 };
 constexpr int kMaxFusedEmbed = 4;
 
@@ -100,6 +101,7 @@ struct NodeArgs {
   const int32_t* out_index;  // [N] or nullptr
   float* out;
   int32_t dbg;            // experiment switches (AMBER_MPN_DBG), 0 in production
+  int32_t single;         // AMBER_PREC_F16, as in EdgeArgs
 };
 
 hipError_t launch_edge(int L, const EdgeArgs& a, hipStream_t s);

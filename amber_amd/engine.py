@@ -13,9 +13,10 @@ from . import _lib
 from .csr import CSR, _require_cuda
 
 
-PRECISIONS = {"fp32": 0, "f16x2": 1}
+PRECISIONS = {"fp32": 0, "f16x2": 1, "f16": 2}
 # Precision of the MLP contractions used by the nn.Module mirrors: "fp32" = exact fp32 MFMA everywhere; "f16x2" =
-# fp32-grade split precision in the edge kernel (include/amber_mpn.h, AMBER_PREC_F16X2).  Both meet the 1e-5 bar.
+# fp32-grade split precision in the edge and node kernels (include/amber_mpn.h, AMBER_PREC_F16X2); both meet the 1e-5
+# bar.  "f16" = plain fp16 operands in the same kernels (tolerance 1e-2, opt-in only).
 default_precision = os.environ.get("AMBER_MPN_PRECISION", "f16x2")
 
 

@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--latent", type=int, default=128)
     ap.add_argument("--mp-steps", type=int, default=10)
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--precision", choices=["fp32", "f16x2", "f16"], default=None,
+                    help="MLP contraction precision (default f16x2: fp32-grade, 1e-5; f16: reduced, 1e-2; fp32: exact fp32 MFMA)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-graphs", type=int, default=10, help="graphs in the CPU-baseline sample (10 = 1M edges)")
     return ap.parse_args()
@@ -69,6 +71,8 @@ def cpu_baseline(cfg, state_dict, args):
 
 def main():
     args = parse()
+    if args.precision:
+        engine.default_precision = args.precision
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))

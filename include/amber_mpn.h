@@ -58,10 +58,13 @@ enum { AMBER_NORM_NONE = 0, AMBER_NORM_LAYER = 1, AMBER_NORM_AFFINE = 2 /* Batch
 /* precision of the MLP contractions */
 enum {
   AMBER_PREC_FP32 = 0, /* exact fp32 MFMA (v_mfma_f32_32x32x2_f32): a k-ordered fmaf chain */
-  AMBER_PREC_F16X2 = 1 /* fp32-grade split precision: operands as hi + lo fp16 pairs (22 bits) with exact
-                          power-of-two row / matrix scaling, 3 fp16 MFMAs per product, fp32 accumulate; meets the
-                          fp32 tolerance (1e-5).  Used by the edge kernel where the configuration allows it
-                          (relu / leakyrelu, no "outer" modes, weights fit LDS), otherwise the exact path runs. */
+  AMBER_PREC_F16X2 = 1, /* fp32-grade split precision: operands as hi + lo fp16 pairs (22 bits) with exact
+                           power-of-two tile / matrix scaling, 3 fp16 MFMAs per product, fp32 accumulate; meets the
+                           fp32 tolerance (1e-5).  Used by the edge and node kernels where the configuration allows
+                           it (relu / leakyrelu, no "outer" modes, weights fit LDS), otherwise the exact path runs. */
+  AMBER_PREC_F16 = 2    /* reduced precision: the same kernels with plain fp16 operands (one MFMA per product, fp32
+                           accumulate, fp32 storage of all features); tolerance 1e-2, the bound BASELINE's north star
+                           gives for bf16-class MLPs.  Never the default. */
 };
 
 /* Static description of the network: the hyper-parameters the reference reads from
