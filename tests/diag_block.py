@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Error pattern of one block application vs the oracle on a golden fixture (GPU).  usage: debug_block.py [fixture]"""
+"""Developer diagnostic (not collected by pytest; lives under tests/ because it uses the oracle): error pattern of one
+block application vs the oracle on a golden fixture, and of the partial sums the edge kernel leaves in the workspace.
+usage (GPU box): python3 tests/diag_block.py [fixture]"""
 import os
 import sys
 
@@ -7,7 +9,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from amber_amd import csr as csr_mod, engine  # noqa: E402
 from oracle import mpn_oracle as orc  # noqa: E402
 import test_gpu_parity as T  # noqa: E402
