@@ -63,10 +63,16 @@ SIGNATURES = {
     "amber_mpn_workspace_bytes": (_SZ, [_DESC, _I64, _I64]),
     "amber_mpn_embed": (C.c_int, [_DESC, _P, _P, _I64, _I64, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "amber_mpn_block": (C.c_int, [_DESC, _P, _P, _I32, _I64, _I64, _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    "amber_mpn_project": (C.c_int, [_DESC, _P, _P, _I32, _I64, _P, _P, _P, _P]),
     "amber_mpn_head": (C.c_int, [_DESC, _P, _P, _I64, _P, _P, _P, _P]),
     "amber_mpn_forward": (C.c_int, [_DESC, _P, _P, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "amber_mpn_forward_timed": (C.c_int, [_DESC, _P, _P, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P,
                                           C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
+    "amber_mpn_tape_bytes": (_SZ, [_DESC, _I64, _I64]),
+    "amber_mpn_forward_train": (C.c_int, [_DESC, _P, _P, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P, _SZ, _P]),
+    "amber_mpn_backward_workspace_bytes": (_SZ, [_DESC, _I64, _I64]),
+    "amber_mpn_backward": (C.c_int, [_DESC, _P, _P, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P, _P,
+                                     _SZ, _P]),
 }
 
 _lib = None

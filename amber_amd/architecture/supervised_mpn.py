@@ -26,7 +26,7 @@ class SupervisedMPN(nn.Module):
     def forward(self, observations, **kwargs) -> torch.Tensor:
         """observations: (batch of) observation graph(s) on the GPU.  Returns one scalar per kept node,
         shape [N_masked, 1] (all nodes when the batch has no `mask_output`)."""
-        csr = self.mpn.prepare(observations)
+        observations, csr = self.mpn.prepare(observations)
         n = csr.num_nodes
         out_index, n_out = None, n
         if hasattr(observations, "mask_output"):
@@ -37,6 +37,13 @@ class SupervisedMPN(nn.Module):
         dec_pieces, dec_sources = dec.param_list(single_row=(n_out == 1))
         base = self.mpn.param_list()
         tail = [self.readout.weight, self.readout.bias]
+        if engine.wants_grad(base + dec_sources + tail):  # training step (src/algorithm/core/amber.py:62-82)
+            if self.training and any(isinstance(m, nn.Dropout) and m.p > 0 for m in dec.mlp_layers):
+                raise NotImplementedError("amber_amd: decoder dropout is not built for training")
+            if dec.latent_normalization is not None:
+                raise NotImplementedError("amber_amd: decoder latent_normalization is not built for training")
+            return engine.MpnFunction.apply(desc, self._packed, observations.x, observations.edge_attr, csr, out_index, n_out,
+                                            False, False, *(base + dec_pieces + tail))[2]
         flat, packed = self._packed.get(desc, base + dec_pieces + tail, key_tensors=base + dec_sources + tail
                                         + ([self.readout.bias] if n_out == 1 else []))
         _, _, out = engine.forward(desc, flat, packed, observations.x, observations.edge_attr, csr, want_node=False,

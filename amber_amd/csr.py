@@ -25,6 +25,23 @@ class CSR:
     perm: torch.Tensor        # int32 [E]: original edge id at sorted position p
 
 
+def source_order(csr: CSR):
+    """(rowptr_src[N+1], perm_src[E]): the CSR positions regrouped by SOURCE node, stable (perm_src[q] = position in the
+    destination-sorted order of the q-th edge in source order).  The backward pass sums the gradients of the gathered
+    P_s[src] terms over it, deterministically.  Built with the same integer sort as the CSR itself; cached on `csr`."""
+    cached = getattr(csr, "_source_order", None)
+    if cached is not None:
+        return cached
+    if csr.num_edges == 0:
+        dev = csr.rowptr.device
+        out = (torch.zeros(csr.num_nodes + 1, dtype=torch.int32, device=dev), torch.zeros(0, dtype=torch.int32, device=dev))
+    else:
+        by_src = build_csr(torch.stack([csr.dst_sorted.long(), csr.src_sorted.long()]), csr.num_nodes, validate=False)
+        out = (by_src.rowptr, by_src.perm)
+    csr._source_order = out
+    return out
+
+
 def _require_cuda(t: torch.Tensor, name: str) -> None:
     if not t.is_cuda:
         raise RuntimeError(

@@ -197,6 +197,21 @@ Workspace carve(const AmberMpnDesc& d, int64_t N, int64_t E, void* base) {
   return w;
 }
 
+// training tape: block inputs of every step, x_t[N,L] and e_t[E,L] (CSR order), t = 0 .. iters
+struct Tape {
+  float *x, *e;
+  size_t bytes;
+};
+Tape carve_tape(const AmberMpnDesc& d, int64_t N, int64_t E, float* base) {
+  const size_t L = static_cast<size_t>(d.latent), T1 = static_cast<size_t>(d.num_steps) * d.num_step_repeats + 1;
+  Tape t;
+  t.x = base;
+  const size_t xb = align256(sizeof(float) * T1 * static_cast<size_t>(N) * L);
+  t.e = reinterpret_cast<float*>(reinterpret_cast<char*>(base) + xb);
+  t.bytes = xb + align256(sizeof(float) * T1 * static_cast<size_t>(E) * L);
+  return t;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // optional per-kernel timing (bench hook)
 // ---------------------------------------------------------------------------------------------------
@@ -375,7 +390,7 @@ int run_embedding(const AmberMpnDesc& d, const MlpLayout& m, int F, const float*
 int forward_impl(const AmberMpnDesc* desc, const float* params, const float* packed, int64_t N, int64_t E, const float* x,
                  const float* edge_attr, const int32_t* rowptr, const int32_t* src_sorted, const int32_t* dst_sorted,
                  const int32_t* perm, const int32_t* out_index, float* out_node, float* out_edge, float* out_sizing,
-                 void* workspace, size_t workspace_bytes, hipStream_t s, Timer& tm) {
+                 void* workspace, size_t workspace_bytes, hipStream_t s, Timer& tm, float* tape = nullptr) {
   int rc = validate(desc);
   if (rc) return rc;
   const AmberMpnDesc& d = *desc;
@@ -392,16 +407,20 @@ int forward_impl(const AmberMpnDesc* desc, const float* params, const float* pac
   const Layout lay = build_layout(d);
   const Workspace w = carve(d, N, E, workspace);
   const int L = d.latent;
-
-  rc = run_embedding(d, lay.node_embed, d.in_node_features, params, packed, x, N, nullptr, w.x, s, tm);
-  if (rc) return rc;
   const int iters = d.num_steps * d.num_step_repeats;
+  // Training: the block inputs of every step are kept (x_t, e_t, t = 0 .. iters) instead of being updated in place.
+  const Tape tp = carve_tape(d, N, E, tape);
+  auto xbuf = [&](int t) { return tape ? tp.x + static_cast<size_t>(t) * N * L : w.x; };
+  auto ebuf = [&](int t) { return tape ? tp.e + static_cast<size_t>(t) * E * L : w.e; };
+
+  rc = run_embedding(d, lay.node_embed, d.in_node_features, params, packed, x, N, nullptr, xbuf(0), s, tm);
+  if (rc) return rc;
   // The linear (or constant) edge embedding of few raw features is fused into the first edge step: its rows are
   // computed there on the fly and e is first written by that step.
-  const bool fuse_edge_embed = iters > 0 && use_fast_edge(d) && d.in_edge_features <= kMaxFusedEmbed &&
+  const bool fuse_edge_embed = !tape && iters > 0 && use_fast_edge(d) && d.in_edge_features <= kMaxFusedEmbed &&
                                (d.in_edge_features == 0 || d.embed_layers == 0) && !getenv("AMBER_MPN_NO_FUSED_EMBED");
   if (!fuse_edge_embed) {
-    rc = run_embedding(d, lay.edge_embed, d.in_edge_features, params, packed, edge_attr, E, perm, w.e, s, tm);
+    rc = run_embedding(d, lay.edge_embed, d.in_edge_features, params, packed, edge_attr, E, perm, ebuf(0), s, tm);
     if (rc) return rc;
   }
 
@@ -409,7 +428,7 @@ int forward_impl(const AmberMpnDesc* desc, const float* params, const float* pac
   if (iters == 0) {
     NodeArgs a{};
     a.N = N;
-    a.x_in = w.x;
+    a.x_in = xbuf(0);
     a.x_out = out_node;
     if (want_head) fill_node_head(a, d, lay, params, packed, out_index, out_sizing);
     if (out_node || want_head) {
@@ -420,7 +439,7 @@ int forward_impl(const AmberMpnDesc* desc, const float* params, const float* pac
     }
     if (out_edge) {
       tm.begin(AMBER_KC_OTHER);
-      hipError_t e = launch_permute_rows(w.e, perm, E, L, 0, out_edge, s);
+      hipError_t e = launch_permute_rows(ebuf(0), perm, E, L, 0, out_edge, s);
       tm.end();
       HIP_TRY(e, "permute kernel");
     }
@@ -429,7 +448,7 @@ int forward_impl(const AmberMpnDesc* desc, const float* params, const float* pac
   {  // first-layer projections of step 0
     NodeArgs a{};
     a.N = N;
-    a.x_in = w.x;
+    a.x_in = xbuf(0);
     fill_node_proj(a, d, lay, 0, params, packed, w.Ps, w.Pd);
     tm.begin(AMBER_KC_NODE);
     hipError_t e = run_node(d, a, s);
@@ -446,7 +465,8 @@ int forward_impl(const AmberMpnDesc* desc, const float* params, const float* pac
     ea.dst = dst_sorted;
     ea.rowptr = rowptr;
     ea.perm = perm;
-    ea.e = w.e;
+    ea.e = ebuf(it);
+    ea.e_out = tape ? ebuf(it + 1) : nullptr;
     ea.Ps = w.Ps;
     ea.Pd = w.Pd;
     fill_edge_step(ea, d, lay, step, params, packed);
@@ -460,7 +480,7 @@ int forward_impl(const AmberMpnDesc* desc, const float* params, const float* pac
       ea.emb_w = d.in_edge_features > 0 ? params + lay.edge_embed.W[0] : nullptr;
       ea.emb_b = params + lay.edge_embed.B[0];
     }
-    ea.write_e = last ? 0 : 1;  // after the last step only the aggregate (and out_edge, if asked for) is needed
+    ea.write_e = (last && !tape) ? 0 : 1;  // after the last step only the aggregate (and out_edge, if asked for) is needed
     ea.out_edge = last ? out_edge : nullptr;
     tm.begin(AMBER_KC_EDGE);
     hipError_t e = run_edge(d, ea, s);
@@ -469,26 +489,287 @@ int forward_impl(const AmberMpnDesc* desc, const float* params, const float* pac
 
     NodeArgs na{};
     na.N = N;
-    na.x_in = w.x;
+    na.x_in = xbuf(it);
     na.rowptr = rowptr;
     na.agg = w.agg;
     na.head = w.head;
     na.tail = w.tail;
     fill_node_update(na, d, lay, step, params, packed);
     if (!last) {
-      na.x_out = w.x;
+      na.x_out = xbuf(it + 1);
       fill_node_proj(na, d, lay, (it + 1) / d.num_step_repeats, params, packed, w.Ps, w.Pd);
     } else {
-      na.x_out = out_node;
+      na.x_out = tape ? xbuf(it + 1) : out_node;
       if (want_head) {
         fill_node_head(na, d, lay, params, packed, out_index, out_sizing);
-        if (na.fast && !out_node) na.x_out = w.x;  // the head runs as a launch of its own on the updated rows
+        if (na.fast && !na.x_out) na.x_out = w.x;  // the head runs as a launch of its own on the updated rows
       }
     }
     tm.begin(AMBER_KC_NODE);
     e = run_node(d, na, s);
     tm.end();
     HIP_TRY(e, "node kernel");
+    if (last && tape && out_node)
+      HIP_TRY(hipMemcpyAsync(out_node, xbuf(it + 1), sizeof(float) * static_cast<size_t>(N) * L, hipMemcpyDeviceToDevice, s),
+              "copy of the final node latents");
+  }
+  return AMBER_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// training: configurations the backward kernels take, workspace, and the launch sequence
+// ---------------------------------------------------------------------------------------------------
+int validate_train(const AmberMpnDesc& d) {
+  if (d.residual == AMBER_MODE_OUTER || d.layer_norm == AMBER_MODE_OUTER)
+    return fail(AMBER_ERR_UNSUPPORTED, "training: 'outer' residual / layer_norm is not built (inner and none are)");
+  if (d.embed_layers > 0) return fail(AMBER_ERR_UNSUPPORTED, "training: MLP input embeddings are not built (linear / constant are)");
+  if (d.has_head) {
+    if (d.decoder_activation > AMBER_ACT_TANH)
+      return fail(AMBER_ERR_UNSUPPORTED, "training: decoder activation id %d (relu, leakyrelu, tanh only)", d.decoder_activation);
+    if (d.decoder_norm != AMBER_NORM_NONE) return fail(AMBER_ERR_UNSUPPORTED, "training: decoder latent_normalization is not built");
+  }
+  return AMBER_OK;
+}
+
+struct BwdWorkspace {
+  float *dX, *dE, *M, *DM, *Ps, *Pd, *dPs, *dPd;
+  float* AN[kMaxLayers];
+  float* DHN[kMaxLayers];
+  float* AE[kMaxLayers];
+  float* DHE[kMaxLayers];
+  float *gpart, *cpart, *lnpart, *epart, *mats;
+  size_t mat_floats;
+  size_t bytes;
+};
+constexpr int kBwdMats = 12;
+BwdWorkspace carve_bwd(const AmberMpnDesc& d, int64_t N, int64_t E, void* base) {
+  const size_t L = static_cast<size_t>(d.latent);
+  const size_t nb = align256(sizeof(float) * static_cast<size_t>(N) * L);
+  const size_t eb = align256(sizeof(float) * static_cast<size_t>(E) * L);
+  char* p = static_cast<char*>(base);
+  size_t off = 0;
+  auto take = [&](size_t n) {
+    float* r = reinterpret_cast<float*>(p + off);
+    off += n;
+    return r;
+  };
+  BwdWorkspace w;
+  w.dX = take(nb);
+  w.M = take(nb);
+  w.DM = take(nb);
+  w.Ps = take(nb);
+  w.Pd = take(nb);
+  w.dPs = take(nb);
+  w.dPd = take(nb);
+  const int nn = d.mlp_layers > d.decoder_layers ? d.mlp_layers : d.decoder_layers;
+  for (int l = 0; l < kMaxLayers; ++l) {
+    w.AN[l] = l < nn ? take(nb) : nullptr;
+    w.DHN[l] = l < nn ? take(nb) : nullptr;
+  }
+  w.dE = take(eb);
+  for (int l = 0; l < kMaxLayers; ++l) {
+    w.AE[l] = l < d.mlp_layers ? take(eb) : nullptr;
+    w.DHE[l] = l < d.mlp_layers ? take(eb) : nullptr;
+  }
+  w.gpart = take(align256(sizeof(float) * kWgradMaxChunks * L * L));
+  w.cpart = take(align256(sizeof(float) * kWgradMaxChunks * L));
+  w.lnpart = take(align256(sizeof(float) * kBwdMaxBlocks * 4 * 2 * L));
+  w.epart = take(align256(sizeof(float) * kWgradMaxChunks * L * 65));
+  w.mat_floats = L * L + kPackedHeader;
+  w.mats = take(align256(sizeof(float) * kBwdMats * w.mat_floats));
+  w.bytes = off;
+  return w;
+}
+
+int backward_impl(const AmberMpnDesc* desc, const float* params, const float* packed, int64_t N, int64_t E, const float* x,
+                  const float* edge_attr, const int32_t* rowptr, const int32_t* src_sorted, const int32_t* dst_sorted,
+                  const int32_t* perm, const int32_t* rowptr_src, const int32_t* perm_src, const int32_t* out_index,
+                  const float* grad_node, const float* grad_edge, const float* grad_sizing, float* tape, float* grad_params,
+                  void* workspace, hipStream_t s) {
+  const AmberMpnDesc& d = *desc;
+  const Layout lay = build_layout(d);
+  const Tape tp = carve_tape(d, N, E, tape);
+  const BwdWorkspace w = carve_bwd(d, N, E, workspace);
+  const int L = d.latent, nl = d.mlp_layers;
+  const int iters = d.num_steps * d.num_step_repeats;
+  const size_t NL = static_cast<size_t>(N) * L, EL = static_cast<size_t>(E) * L;
+  auto xbuf = [&](int t) { return tp.x + static_cast<size_t>(t) * NL; };
+  auto ebuf = [&](int t) { return tp.e + static_cast<size_t>(t) * EL; };
+  float* const g = grad_params;
+  auto mat = [&](int i) { return w.mats + static_cast<size_t>(i) * w.mat_floats; };
+
+  HIP_TRY(hipMemsetAsync(g, 0, sizeof(float) * static_cast<size_t>(lay.n_params), s), "clear gradients");
+  if (N == 0) return AMBER_OK;
+  if (grad_node)
+    HIP_TRY(hipMemcpyAsync(w.dX, grad_node, sizeof(float) * NL, hipMemcpyDeviceToDevice, s), "grad_node");
+  else
+    HIP_TRY(hipMemsetAsync(w.dX, 0, sizeof(float) * NL, s), "clear dX");
+  if (E > 0) {
+    if (grad_edge)
+      HIP_TRY(launch_permute_rows(grad_edge, perm, E, L, 1, w.dE, s), "grad_edge to CSR order");
+    else
+      HIP_TRY(hipMemsetAsync(w.dE, 0, sizeof(float) * EL, s), "clear dE");
+  }
+  const int gn = chain_bwd_grid(N) * 4, ge = chain_bwd_grid(E) * 4;
+
+  // ---- SupervisedMPN head: readout(decoder(x_T[mask])) ----
+  if (d.has_head && grad_sizing) {
+    const int nd = d.decoder_layers;
+    ChainBwdArgs a{};
+    a.mode = AMBER_BWD_HEAD;
+    a.rows = N;
+    a.rin = xbuf(iters);
+    a.nl = nd;
+    a.act = d.decoder_activation;
+    a.residual = AMBER_MODE_NONE;
+    a.layer_norm = AMBER_MODE_NONE;
+    a.eps = d.ln_eps;
+    for (int l = 0; l < nd; ++l) {
+      HIP_TRY(launch_pack(L, params + lay.dec.W[l], L, 0, mat(2 * l), s), "pack decoder");
+      HIP_TRY(launch_pack_t(L, params + lay.dec.W[l], L, 0, mat(2 * l + 1), s), "pack decoder^T");
+      if (l == 0) {
+        a.w_in = mat(0);
+        a.wT_in = mat(1);
+        a.b0 = params + lay.dec.B[0];
+      } else {
+        a.layers[l] = DenseLayer{mat(2 * l), params + lay.dec.B[l], nullptr, nullptr};
+        a.wT[l] = mat(2 * l + 1);
+      }
+      a.A[l] = w.AN[l];
+      a.DH[l] = w.DHN[l];
+    }
+    a.dio = w.dX;
+    a.dout = grad_sizing;
+    a.out_index = out_index;
+    a.wr = params + lay.readout_w;
+    a.part = w.lnpart;
+    HIP_TRY(launch_chain_bwd(L, a, s), "head backward kernel");
+    HIP_TRY(launch_colpart_reduce(w.lnpart, gn, L, g + lay.readout_w, L, g + lay.readout_b, 1, s), "readout gradient");
+    for (int l = 0; l < nd; ++l)
+      HIP_TRY(launch_wgrad(L, w.DHN[l], l == 0 ? xbuf(iters) : w.AN[l - 1], N, g + lay.dec.W[l], L, 0, g + lay.dec.B[l], w.gpart,
+                           w.cpart, s),
+              "decoder weight gradient");
+  }
+
+  for (int it = iters - 1; it >= 0; --it) {
+    const int step = it / d.num_step_repeats;
+    const MlpLayout& mn = lay.node[step];
+    const MlpLayout& me = lay.edge[step];
+    const float* x_in = xbuf(it);
+    const float* e_in = ebuf(it);
+    const bool ln = d.layer_norm == AMBER_MODE_INNER;
+    // ---- node module: x' = LN(MLP([x, mean(e')]) + x) ----
+    if (E > 0)
+      HIP_TRY(launch_segment_reduce(ebuf(it + 1), rowptr, nullptr, N, L, 1, w.M, s), "mean aggregate");
+    else
+      HIP_TRY(hipMemsetAsync(w.M, 0, sizeof(float) * NL, s), "clear M");
+    {
+      ChainBwdArgs a{};
+      a.mode = AMBER_BWD_NODE;
+      a.rows = N;
+      a.rin = x_in;
+      a.m = w.M;
+      a.nl = nl;
+      a.act = d.activation;
+      a.residual = d.residual;
+      a.layer_norm = d.layer_norm;
+      a.gamma = ln ? params + lay.ng[step] : nullptr;
+      a.eps = d.ln_eps;
+      HIP_TRY(launch_pack(L, params + mn.W[0], 2 * L, 0, mat(0), s), "pack W0x");
+      HIP_TRY(launch_pack_t(L, params + mn.W[0], 2 * L, 0, mat(1), s), "pack W0x^T");
+      HIP_TRY(launch_pack(L, params + mn.W[0], 2 * L, L, mat(2), s), "pack W0a");
+      HIP_TRY(launch_pack_t(L, params + mn.W[0], 2 * L, L, mat(3), s), "pack W0a^T");
+      a.w_in = mat(0);
+      a.wT_in = mat(1);
+      a.w_m = mat(2);
+      a.wT_m = mat(3);
+      a.b0 = params + mn.B[0];
+      for (int l = 1; l < nl; ++l) {
+        HIP_TRY(launch_pack(L, params + mn.W[l], L, 0, mat(2 + 2 * l), s), "pack node W_l");
+        HIP_TRY(launch_pack_t(L, params + mn.W[l], L, 0, mat(3 + 2 * l), s), "pack node W_l^T");
+        a.layers[l] = DenseLayer{mat(2 + 2 * l), params + mn.B[l], nullptr, nullptr};
+        a.wT[l] = mat(3 + 2 * l);
+      }
+      for (int l = 0; l < nl; ++l) {
+        a.A[l] = w.AN[l];
+        a.DH[l] = w.DHN[l];
+      }
+      a.dio = w.dX;
+      a.dm_out = w.DM;
+      a.part = ln ? w.lnpart : nullptr;
+      HIP_TRY(launch_chain_bwd(L, a, s), "node backward kernel");
+      if (ln) HIP_TRY(launch_colpart_reduce(w.lnpart, gn, L, g + lay.ng[step], L, g + lay.nb[step], L, s), "node LayerNorm gradient");
+      HIP_TRY(launch_wgrad(L, w.DHN[0], x_in, N, g + mn.W[0], 2 * L, 0, g + mn.B[0], w.gpart, w.cpart, s), "dW0x");
+      HIP_TRY(launch_wgrad(L, w.DHN[0], w.M, N, g + mn.W[0], 2 * L, L, nullptr, w.gpart, w.cpart, s), "dW0a");
+      for (int l = 1; l < nl; ++l)
+        HIP_TRY(launch_wgrad(L, w.DHN[l], w.AN[l - 1], N, g + mn.W[l], L, 0, g + mn.B[l], w.gpart, w.cpart, s), "node dW_l");
+    }
+    if (E == 0) continue;
+    // ---- edge module: e' = LN(MLP([x_s, x_d, e]) + e), first layer split into P_s[src] + P_d[dst] + W0e e ----
+    {
+      NodeArgs pa{};
+      pa.N = N;
+      pa.x_in = x_in;
+      fill_node_proj(pa, d, lay, step, params, packed, w.Ps, w.Pd);
+      HIP_TRY(run_node(d, pa, s), "projection recompute");
+      ChainBwdArgs a{};
+      a.mode = AMBER_BWD_EDGE;
+      a.rows = E;
+      a.rin = e_in;
+      a.Ps = w.Ps;
+      a.Pd = w.Pd;
+      a.src = src_sorted;
+      a.dst = dst_sorted;
+      a.rowptr = rowptr;
+      a.nl = nl;
+      a.act = d.activation;
+      a.residual = d.residual;
+      a.layer_norm = d.layer_norm;
+      a.gamma = ln ? params + lay.eg[step] : nullptr;
+      a.eps = d.ln_eps;
+      HIP_TRY(launch_pack(L, params + me.W[0], 3 * L, 2 * L, mat(0), s), "pack W0e");
+      HIP_TRY(launch_pack_t(L, params + me.W[0], 3 * L, 2 * L, mat(1), s), "pack W0e^T");
+      a.w_in = mat(0);
+      a.wT_in = mat(1);
+      for (int l = 1; l < nl; ++l) {
+        HIP_TRY(launch_pack(L, params + me.W[l], L, 0, mat(2 * l), s), "pack edge W_l");
+        HIP_TRY(launch_pack_t(L, params + me.W[l], L, 0, mat(2 * l + 1), s), "pack edge W_l^T");
+        a.layers[l] = DenseLayer{mat(2 * l), params + me.B[l], nullptr, nullptr};
+        a.wT[l] = mat(2 * l + 1);
+      }
+      for (int l = 0; l < nl; ++l) {
+        a.A[l] = w.AE[l];
+        a.DH[l] = w.DHE[l];
+      }
+      a.dio = w.dE;
+      a.dm_in = w.DM;
+      a.part = ln ? w.lnpart : nullptr;
+      HIP_TRY(launch_chain_bwd(L, a, s), "edge backward kernel");
+      if (ln) HIP_TRY(launch_colpart_reduce(w.lnpart, ge, L, g + lay.eg[step], L, g + lay.eb[step], L, s), "edge LayerNorm gradient");
+      HIP_TRY(launch_wgrad(L, w.DHE[0], e_in, E, g + me.W[0], 3 * L, 2 * L, nullptr, w.gpart, w.cpart, s), "dW0e");
+      for (int l = 1; l < nl; ++l)
+        HIP_TRY(launch_wgrad(L, w.DHE[l], w.AE[l - 1], E, g + me.W[l], L, 0, g + me.B[l], w.gpart, w.cpart, s), "edge dW_l");
+      // gathered first-layer terms: gradients summed per destination (CSR rows) and per source (source-sorted order)
+      HIP_TRY(launch_segment_reduce(w.DHE[0], rowptr, nullptr, N, L, 0, w.dPd, s), "dP_d");
+      HIP_TRY(launch_segment_reduce(w.DHE[0], rowptr_src, perm_src, N, L, 0, w.dPs, s), "dP_s");
+      HIP_TRY(launch_wgrad(L, w.dPs, x_in, N, g + me.W[0], 3 * L, 0, nullptr, w.gpart, w.cpart, s), "dW0s");
+      HIP_TRY(launch_wgrad(L, w.dPd, x_in, N, g + me.W[0], 3 * L, L, g + me.B[0], w.gpart, w.cpart, s), "dW0d");
+      HIP_TRY(launch_pack_t(L, params + me.W[0], 3 * L, 0, mat(10), s), "pack W0s^T");
+      HIP_TRY(launch_pack_t(L, params + me.W[0], 3 * L, L, mat(11), s), "pack W0d^T");
+      HIP_TRY(launch_rows_gemm_add(L, w.dX, w.dPs, mat(10), w.dPd, mat(11), N, s), "dx from the projections");
+    }
+  }
+  // ---- input embeddings (src/mpn/input_embedding.py:41-42) ----
+  {
+    const MlpLayout& m = lay.node_embed;
+    const int F = d.in_node_features;
+    HIP_TRY(launch_embed_bwd(L, w.dX, x, nullptr, N, F, F > 0 ? g + m.W[0] : nullptr, g + m.B[0], w.epart, s), "node embedding gradient");
+  }
+  if (E > 0) {
+    const MlpLayout& m = lay.edge_embed;
+    const int F = d.in_edge_features;
+    HIP_TRY(launch_embed_bwd(L, w.dE, edge_attr, perm, E, F, F > 0 ? g + m.W[0] : nullptr, g + m.B[0], w.epart, s),
+            "edge embedding gradient");
   }
   return AMBER_OK;
 }
@@ -681,6 +962,23 @@ int amber_mpn_block(const AmberMpnDesc* desc, const float* params, const float* 
   return AMBER_OK;
 }
 
+int amber_mpn_project(const AmberMpnDesc* desc, const float* params, const float* packed, int32_t step, int64_t num_nodes,
+                      const float* x_latent, float* p_src, float* p_dst, void* stream) {
+  int rc = validate(desc);
+  if (rc) return rc;
+  if (step < 0 || step >= desc->num_steps) return fail(AMBER_ERR_INVALID_ARGUMENT, "step %d out of range", step);
+  if (!params || !packed) return fail(AMBER_ERR_INVALID_ARGUMENT, "params / packed is NULL");
+  if (num_nodes == 0) return AMBER_OK;
+  if (!x_latent || !p_src || !p_dst) return fail(AMBER_ERR_INVALID_ARGUMENT, "x_latent / p_src / p_dst is NULL");
+  const Layout lay = build_layout(*desc);
+  NodeArgs pa{};
+  pa.N = num_nodes;
+  pa.x_in = x_latent;
+  fill_node_proj(pa, *desc, lay, step, params, packed, p_src, p_dst);
+  HIP_TRY(run_node(*desc, pa, static_cast<hipStream_t>(stream)), "node projection kernel");
+  return AMBER_OK;
+}
+
 int amber_mpn_head(const AmberMpnDesc* desc, const float* params, const float* packed, int64_t num_nodes, const float* x_latent,
                    const int32_t* out_index, float* out_sizing, void* stream) {
   int rc = validate(desc);
@@ -721,6 +1019,63 @@ int amber_mpn_forward_timed(const AmberMpnDesc* desc, const float* params, const
                         out_node, out_edge, out_sizing, workspace ? aligned_ws(workspace) : nullptr, workspace_bytes, tm.s, tm);
   tm.collect(kernel_ms, kernel_launches);
   return rc;
+}
+
+size_t amber_mpn_tape_bytes(const AmberMpnDesc* desc, int64_t num_nodes, int64_t num_edges) {
+  if (validate(desc) || num_nodes < 0 || num_edges < 0) return 0;
+  return carve_tape(*desc, num_nodes, num_edges, nullptr).bytes + 256;
+}
+
+int amber_mpn_forward_train(const AmberMpnDesc* desc, const float* params, const float* packed, int64_t num_nodes, int64_t num_edges,
+                            const float* x, const float* edge_attr, const int32_t* rowptr, const int32_t* src_sorted,
+                            const int32_t* dst_sorted, const int32_t* perm, const int32_t* out_index, float* out_node, float* out_edge,
+                            float* out_sizing, void* tape, size_t tape_bytes, void* workspace, size_t workspace_bytes, void* stream) {
+  int rc = validate(desc);
+  if (rc) return rc;
+  rc = validate_train(*desc);
+  if (rc) return rc;
+  if (!tape) return fail(AMBER_ERR_INVALID_ARGUMENT, "tape is NULL");
+  if (tape_bytes < amber_mpn_tape_bytes(desc, num_nodes, num_edges))
+    return fail(AMBER_ERR_WORKSPACE_TOO_SMALL, "tape %zu < %zu bytes", tape_bytes, amber_mpn_tape_bytes(desc, num_nodes, num_edges));
+  Timer tm;
+  return forward_impl(desc, params, packed, num_nodes, num_edges, x, edge_attr, rowptr, src_sorted, dst_sorted, perm, out_index,
+                      out_node, out_edge, out_sizing, workspace ? aligned_ws(workspace) : nullptr, workspace_bytes,
+                      static_cast<hipStream_t>(stream), tm, static_cast<float*>(aligned_ws(tape)));
+}
+
+size_t amber_mpn_backward_workspace_bytes(const AmberMpnDesc* desc, int64_t num_nodes, int64_t num_edges) {
+  if (validate(desc) || num_nodes < 0 || num_edges < 0) return 0;
+  const size_t fw = amber_mpn_workspace_bytes(desc, num_nodes, num_edges);
+  const size_t bw = carve_bwd(*desc, num_nodes, num_edges, nullptr).bytes + 256;
+  return fw > bw ? fw : bw;
+}
+
+int amber_mpn_backward(const AmberMpnDesc* desc, const float* params, const float* packed, int64_t num_nodes, int64_t num_edges,
+                       const float* x, const float* edge_attr, const int32_t* rowptr, const int32_t* src_sorted,
+                       const int32_t* dst_sorted, const int32_t* perm, const int32_t* rowptr_src, const int32_t* perm_src,
+                       const int32_t* out_index, const float* grad_node, const float* grad_edge, const float* grad_sizing,
+                       void* tape, size_t tape_bytes, float* grad_params, void* workspace, size_t workspace_bytes, void* stream) {
+  int rc = validate(desc);
+  if (rc) return rc;
+  rc = validate_train(*desc);
+  if (rc) return rc;
+  const int64_t N = num_nodes, E = num_edges;
+  if (N < 0 || E < 0 || N >= (1ll << 31) || E >= (1ll << 31)) return fail(AMBER_ERR_INVALID_ARGUMENT, "N / E out of int32 range");
+  if (!params || !packed || !tape || !grad_params || !workspace)
+    return fail(AMBER_ERR_INVALID_ARGUMENT, "params / packed / tape / grad_params / workspace is NULL");
+  if (N > 0 && desc->in_node_features > 0 && !x) return fail(AMBER_ERR_INVALID_ARGUMENT, "x is NULL");
+  if (E > 0 && desc->in_edge_features > 0 && !edge_attr) return fail(AMBER_ERR_INVALID_ARGUMENT, "edge_attr is NULL");
+  if (E > 0 && (!rowptr || !src_sorted || !dst_sorted || !perm || !rowptr_src || !perm_src))
+    return fail(AMBER_ERR_INVALID_ARGUMENT, "CSR arrays are NULL");
+  if (N > 0 && !rowptr) return fail(AMBER_ERR_INVALID_ARGUMENT, "rowptr is NULL");
+  if (grad_sizing && !desc->has_head) return fail(AMBER_ERR_INVALID_ARGUMENT, "grad_sizing given but desc->has_head == 0");
+  if (tape_bytes < amber_mpn_tape_bytes(desc, N, E)) return fail(AMBER_ERR_WORKSPACE_TOO_SMALL, "tape too small");
+  if (workspace_bytes < amber_mpn_backward_workspace_bytes(desc, N, E))
+    return fail(AMBER_ERR_WORKSPACE_TOO_SMALL, "workspace %zu < %zu bytes", workspace_bytes,
+                amber_mpn_backward_workspace_bytes(desc, N, E));
+  return backward_impl(desc, params, packed, N, E, x, edge_attr, rowptr, src_sorted, dst_sorted, perm, rowptr_src, perm_src, out_index,
+                       grad_node, grad_edge, grad_sizing, static_cast<float*>(aligned_ws(tape)), grad_params, aligned_ws(workspace),
+                       static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

@@ -346,6 +346,7 @@ __global__ __launch_bounds__(kF2Block) void edge_kernel_f2(const EdgeArgs a, con
     const int64_t p0 = tile * kTile;
     const int nvalid = (a.E - p0) < kTile ? static_cast<int>(a.E - p0) : kTile;  // >= 1: tile < ntiles
     float* const et = a.e + p0 * L;     // this tile's rows of e (wave-uniform base, 32-bit lane offsets)
+    float* const eo = (a.e_out ? a.e_out : a.e) + p0 * L;  // where the updated rows go (training tape: not in place)
     const int rlim = nvalid - 1;
     // Lane offsets of the direct row accesses are recomputed per tile from these opaque copies: hoisted out of the tile
     // loop they would occupy dozens of registers for its whole length.
@@ -493,7 +494,7 @@ __global__ __launch_bounds__(kF2Block) void edge_kernel_f2(const EdgeArgs a, con
           for (int i = 0; i < 16; ++i) {
             const unsigned off = static_cast<unsigned>(hq + (8 * (i >> 2) + (i & 3)) * L);
 #pragma unroll
-            for (int fb = 0; fb < NFB; ++fb) et[off + 32 * fb] = acc.a[fb][i];
+            for (int fb = 0; fb < NFB; ++fb) eo[off + 32 * fb] = acc.a[fb][i];
           }
         } else {
 #pragma unroll
@@ -501,7 +502,7 @@ __global__ __launch_bounds__(kF2Block) void edge_kernel_f2(const EdgeArgs a, con
             const int r = 8 * (i >> 2) + (i & 3) + 4 * h;
             if (r < nvalid) {
 #pragma unroll
-              for (int fb = 0; fb < NFB; ++fb) et[static_cast<unsigned>(hq + (8 * (i >> 2) + (i & 3)) * L) + 32 * fb] = acc.a[fb][i];
+              for (int fb = 0; fb < NFB; ++fb) eo[static_cast<unsigned>(hq + (8 * (i >> 2) + (i & 3)) * L) + 32 * fb] = acc.a[fb][i];
             }
           }
         }

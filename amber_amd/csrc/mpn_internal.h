@@ -28,6 +28,7 @@ struct EdgeArgs {
   const int32_t* rowptr;  // [N+1]
   const int32_t* perm;    // [E] or nullptr (only for out_edge)
   float* e;               // [E,L] latent edge features, CSR order, updated in place
+  float* e_out;           // [E,L] where the updated rows go instead (training tape), or nullptr: in place
   const float* Ps;        // [N,L]  W0[:, 0:L] x          (source part of the first layer)
   const float* Pd;        // [N,L]  W0[:, L:2L] x + b0    (destination part + bias)
   const float* w0e;       // packed W0[:, 2L:3L]
@@ -123,6 +124,61 @@ bool node_f2_supported(int L, int act, int residual, int layer_norm);
 hipError_t launch_segment_mean(const float* vals, const int32_t* rowptr, int64_t N, int L, float* out, hipStream_t s);
 hipError_t launch_permute_rows(const float* in, const int32_t* perm, int64_t rows, int width, int gather, float* out,
                                hipStream_t s);
+
+// ---- backward (training), mpn_bwd.hip ----
+enum { AMBER_BWD_EDGE = 0, AMBER_BWD_NODE = 1, AMBER_BWD_HEAD = 2 };
+constexpr int kBwdMaxBlocks = 1024;    // persistent grid of the chain kernel (4 waves a block)
+constexpr int kWgradMaxChunks = 512;   // split-K chunks of a weight-gradient product
+// Recompute + chain rule of one module on 32-row tiles (see chain_bwd_kernel).  All matrices in the exact fp32 operand
+// order (launch_pack / launch_pack_t).
+struct ChainBwdArgs {
+  int32_t mode;           // AMBER_BWD_*
+  int64_t rows;           // E (edge) or N (node, head)
+  const float* rin;       // [rows,L] streamed input of the first layer and residual term: e_in / x_in
+  const float* Ps;        // edge: [N,L] source part of the first layer
+  const float* Pd;        // edge: [N,L] destination part + bias
+  const int32_t* src;     // edge: [E] sorted
+  const int32_t* dst;     // edge: [E] sorted
+  const int32_t* rowptr;  // edge: [N+1]
+  const float* m;         // node: [N,L] mean of the incoming (updated) edge features
+  const float* w_in;      // first-layer matrix applied to rin (W0e / W0x / decoder W0)
+  const float* w_m;       // node: W0a
+  const float* b0;        // node, head: first-layer bias (edge: inside Pd)
+  DenseLayer layers[kMaxLayers];  // layers[1..nl-1]
+  const float* wT_in;     // transposes of the above
+  const float* wT_m;
+  const float* wT[kMaxLayers];
+  int32_t nl;             // layers of the chain (head: may be 0)
+  int32_t act;
+  int32_t residual;       // AMBER_MODE_NONE / INNER
+  int32_t layer_norm;     // AMBER_MODE_NONE / INNER
+  const float* gamma;
+  float eps;
+  float* dio;             // [rows,L] in: gradient at the module's output; out: gradient at rin (head: added to)
+  const float* dm_in;     // edge: [N,L] gradient at the mean aggregate (divided by the in-degree here)
+  const float* dout;      // head: [N_m] gradient at the readout
+  const int32_t* out_index;  // head: [N] or nullptr
+  const float* wr;        // head: readout weight [L]
+  float* dm_out;          // node: [N,L] gradient at the mean aggregate
+  float* A[kMaxLayers];   // [rows,L] output of layer l (l < nl-1)
+  float* DH[kMaxLayers];  // [rows,L] gradient at the pre-activation of layer l
+  float* part;            // [grid waves][2][L] partial column sums: LayerNorm (d gamma, d beta) or readout (d wr, d br)
+};
+int chain_bwd_grid(int64_t rows);
+hipError_t launch_chain_bwd(int L, const ChainBwdArgs& a, hipStream_t s);
+hipError_t launch_colpart_reduce(const float* part, int G, int L, float* out0, int n0, float* out1, int n1, hipStream_t s);
+int wgrad_chunks(int64_t M, int64_t* chunk_out);
+// dW[:, col0:col0+L] += A^T B (A, B: [M,L]); db += column sums of A (db may be nullptr)
+hipError_t launch_wgrad(int L, const float* A, const float* B, int64_t M, float* dW, int ld, int col0, float* db, float* part,
+                        float* cpart, hipStream_t s);
+int embed_bwd_chunks(int64_t rows, int64_t* chunk_out);
+hipError_t launch_embed_bwd(int L, const float* d, const float* raw, const int32_t* perm, int64_t rows, int F, float* dW, float* db,
+                            float* part, hipStream_t s);
+hipError_t launch_segment_reduce(const float* vals, const int32_t* rowptr, const int32_t* idx, int64_t N, int L, int mean, float* out,
+                                 hipStream_t s);
+hipError_t launch_rows_gemm_add(int L, float* io, const float* in0, const float* w0, const float* in1, const float* w1, int64_t rows,
+                                hipStream_t s);
+hipError_t launch_pack_t(int L, const float* W, int ld, int col0, float* out, hipStream_t s);
 
 size_t csr_workspace_bytes(int64_t N, int64_t E);
 hipError_t csr_build(const int64_t* edge_index, int64_t E, int64_t N, int32_t* rowptr, int32_t* src_sorted,

@@ -112,7 +112,7 @@ __global__ __launch_bounds__(kBlock) void edge_kernel(const EdgeArgs a, const in
     tile_stage<L>(stage, acc, c, h);
     __syncthreads();
   }
-  if (a.write_e) stage_store_rows<L>(stage, a.e, p0, nvalid, nullptr, lane);
+  if (a.write_e) stage_store_rows<L>(stage, a.e_out ? a.e_out : a.e, p0, nvalid, nullptr, lane);
   if (a.out_edge) stage_store_rows<L>(stage, a.out_edge, p0, nvalid, a.perm, lane);
 }
 

@@ -10,7 +10,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from .csr import CSR, _require_cuda
+from .csr import CSR, _require_cuda, source_order
 
 
 PRECISIONS = {"fp32": 0, "f16x2": 1, "f16": 2}
@@ -162,6 +162,19 @@ def block(desc, flat, packed, step: int, x_latent: torch.Tensor, e_latent_sorted
     _lib.check(rc, "block")
 
 
+def project(desc, flat, packed, step: int, x_latent: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """amber_mpn_project: (P_s, P_d) = (W0s x, W0d x + b0) of block `step`'s edge MLP."""
+    lib = _lib.load()
+    dev = x_latent.device
+    x_latent = _f32c(x_latent)
+    ps, pd = torch.empty_like(x_latent), torch.empty_like(x_latent)
+    with torch.cuda.device(dev):
+        rc = lib.amber_mpn_project(C.byref(desc), flat.data_ptr(), packed.data_ptr(), step, int(x_latent.shape[0]),
+                                   x_latent.data_ptr(), ps.data_ptr(), pd.data_ptr(), _lib.stream_ptr(dev))
+    _lib.check(rc, "project")
+    return ps, pd
+
+
 def head(desc, flat, packed, x_latent: torch.Tensor, out_index: Optional[torch.Tensor], n_out: int) -> torch.Tensor:
     """amber_mpn_head: readout(decoder(x_latent[mask]))."""
     lib = _lib.load()
@@ -172,3 +185,104 @@ def head(desc, flat, packed, x_latent: torch.Tensor, out_index: Optional[torch.T
                                 _lib.ptr(out_index), out.data_ptr(), _lib.stream_ptr(dev))
     _lib.check(rc, "head")
     return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# training: forward that keeps the per-step block inputs on a tape + backward (amber_mpn_backward), as one
+# torch.autograd.Function over the module's parameters
+# ---------------------------------------------------------------------------------------------------
+# How parameter gradients are combined across ranks when torch.distributed is initialised (graph-wise data
+# parallelism): one all-reduce of the single flat gradient buffer per backward ("mean" = DistributedDataParallel's
+# convention, "sum", or None = leave the gradients local).
+grad_sync: Optional[str] = "mean"
+debug_keep_backward_workspace: Optional[list] = None  # developer diagnostics: set to a list to receive the workspaces
+
+
+def _sync_flat_gradient(flat_grad: torch.Tensor) -> None:
+    import torch.distributed as dist
+
+    if grad_sync is None or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)  # RCCL over xGMI on the GPU box (backend "nccl"); one bucket
+    if grad_sync == "mean":
+        flat_grad.div_(dist.get_world_size())
+
+
+class MpnFunction(torch.autograd.Function):
+    """(node[N,L], edge[E,L], sizing[n_out,1]) = f(parameters); unwanted outputs are empty tensors.
+    Inputs x / edge_attr are data and get no gradient."""
+
+    @staticmethod
+    def forward(ctx, desc, packer: PackedParams, x, edge_attr, csr: CSR, out_index, n_out, want_node, want_edge, *params):
+        lib = _lib.load()
+        _require_cuda(x, "x")
+        _require_cuda(edge_attr, "edge_attr")
+        dev = x.device
+        x, edge_attr = _f32c(x), _f32c(edge_attr)
+        n, e, latent = csr.num_nodes, csr.num_edges, desc.latent
+        if x.shape[0] != n or edge_attr.shape[0] != e:
+            raise ValueError(f"Must provide one edge index per edge feature vector, given '{(2, e)}' and '{tuple(edge_attr.shape)}' instead.")
+        flat, packed = packer.get(desc, params)
+        out_node = torch.empty(n, latent, dtype=torch.float32, device=dev) if want_node else None
+        out_edge = torch.empty(e, latent, dtype=torch.float32, device=dev) if want_edge else None
+        out_sizing = torch.empty(n_out, 1, dtype=torch.float32, device=dev) if (desc.has_head and n_out is not None) else None
+        tape_bytes = lib.amber_mpn_tape_bytes(C.byref(desc), n, e)
+        if tape_bytes == 0:
+            _lib.check(-2, "network description")
+        tape = torch.empty(tape_bytes, dtype=torch.uint8, device=dev)
+        ws = workspace(desc, n, e, dev)
+        with torch.cuda.device(dev):
+            rc = lib.amber_mpn_forward_train(
+                C.byref(desc), flat.data_ptr(), packed.data_ptr(), n, e, _lib.ptr(x), _lib.ptr(edge_attr), csr.rowptr.data_ptr(),
+                _lib.ptr(csr.src_sorted), _lib.ptr(csr.dst_sorted), _lib.ptr(csr.perm), _lib.ptr(out_index), _lib.ptr(out_node),
+                _lib.ptr(out_edge), _lib.ptr(out_sizing), tape.data_ptr(), tape.numel(), ws.data_ptr(), ws.numel(),
+                _lib.stream_ptr(dev))
+        _lib.check(rc, "forward_train")
+        ctx.desc, ctx.csr, ctx.out_index = desc, csr, out_index
+        ctx.x, ctx.edge_attr, ctx.flat, ctx.packed, ctx.tape = x, edge_attr, flat, packed, tape
+        ctx.shapes = [tuple(p.shape) for p in params]
+        ctx.has = (want_node, want_edge, out_sizing is not None)
+        empty = torch.empty(0, dtype=torch.float32, device=dev)
+        outs = (out_node if want_node else empty, out_edge if want_edge else empty, out_sizing if out_sizing is not None else empty)
+        ctx.mark_non_differentiable(*[o for o, h in zip(outs, ctx.has) if not h])
+        return outs
+
+    @staticmethod
+    def backward(ctx, g_node, g_edge, g_sizing):
+        lib = _lib.load()
+        desc, csr = ctx.desc, ctx.csr
+        dev = ctx.x.device
+        n, e = csr.num_nodes, csr.num_edges
+        want_node, want_edge, has_sizing = ctx.has
+        g_node = _f32c(g_node) if want_node and g_node is not None else None
+        g_edge = _f32c(g_edge) if want_edge and g_edge is not None else None
+        g_sizing = _f32c(g_sizing) if has_sizing and g_sizing is not None else None
+        rowptr_src, perm_src = source_order(csr)
+        grad = torch.empty(ctx.flat.numel(), dtype=torch.float32, device=dev)
+        ws_bytes = lib.amber_mpn_backward_workspace_bytes(C.byref(desc), n, e)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.amber_mpn_backward(
+                C.byref(desc), ctx.flat.data_ptr(), ctx.packed.data_ptr(), n, e, _lib.ptr(ctx.x), _lib.ptr(ctx.edge_attr),
+                csr.rowptr.data_ptr(), _lib.ptr(csr.src_sorted), _lib.ptr(csr.dst_sorted), _lib.ptr(csr.perm),
+                _lib.ptr(rowptr_src), _lib.ptr(perm_src), _lib.ptr(ctx.out_index), _lib.ptr(g_node), _lib.ptr(g_edge),
+                _lib.ptr(g_sizing), ctx.tape.data_ptr(), ctx.tape.numel(), grad.data_ptr(), ws.data_ptr(), ws.numel(),
+                _lib.stream_ptr(dev))
+        _lib.check(rc, "backward")
+        ctx.tape = None
+        if debug_keep_backward_workspace is not None:
+            debug_keep_backward_workspace.append(ws)
+        _sync_flat_gradient(grad)
+        grads, off = [], 0
+        for shape in ctx.shapes:
+            k = 1
+            for d in shape:
+                k *= d
+            grads.append(grad[off:off + k].view(shape))
+            off += k
+        return (None,) * 9 + tuple(grads)
+
+
+def wants_grad(params: Sequence[torch.Tensor]) -> bool:
+    """The autograd path runs when gradients are being recorded for at least one parameter."""
+    return torch.is_grad_enabled() and any(p.requires_grad for p in params)

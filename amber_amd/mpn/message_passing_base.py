@@ -10,7 +10,7 @@ import torch
 from torch import nn
 
 from amber_amd import engine
-from amber_amd.csr import CSRCache, csr_of
+from amber_amd.csr import CSRCache, build_csr, csr_of
 from amber_amd.mpn.common.mpn_util import get_create_copy, noop, unpack_features
 from amber_amd.mpn.graph_assertions import MessagePassingGraphAssertions
 from amber_amd.mpn.input_embedding import MessagePassingInputEmbedding
@@ -22,10 +22,17 @@ class _LatentGraph:
 
     def __init__(self, source, x, edge_attr):
         self.__dict__.update({k: v for k, v in getattr(source, "__dict__", {}).items()})
+        self.__dict__["_amber_source"] = source
         self.x, self.edge_attr, self.edge_index = x, edge_attr, source.edge_index
         batch = getattr(source, "batch", None)
         if batch is not None:
             self.batch = batch
+
+    def __getattr__(self, name):  # anything else (mask_output, ptr, y, ... of a PyG Batch) is read through
+        source = self.__dict__.get("_amber_source")
+        if source is None or name.startswith("__"):
+            raise AttributeError(name)
+        return getattr(source, name)
 
 
 class MessagePassingBase(nn.Module):
@@ -80,14 +87,16 @@ class MessagePassingBase(nn.Module):
         return self.input_embeddings.param_list() + self.message_passing_stack.param_list()
 
     def prepare(self, graph):
-        """The reference's pre-amble (message_passing_base.py:141-143) and the per-mesh CSR."""
+        """The reference's pre-amble (message_passing_base.py:141-143: assertions, copy, edge dropout) and the CSR.
+        Returns (graph to compute on, csr).  Eval: the caller's graph and the per-mesh cached CSR.  Training with edge
+        dropout: a private shallow view holding the kept edges (the caller's graph is only touched when
+        create_graph_copy=False, as in the reference) and a CSR of its own, since every draw changes the edge list."""
         self.maybe_assertions(graph)
-        if self.training:
-            raise NotImplementedError(
-                "amber_amd: only the inference forward (module.eval()) is built; training needs the backward kernels "
-                "and mask-aware edge dropout (SURVEY.md section 8f, rank 1).")
-        self.maybe_edge_dropout(graph)  # identity in eval mode
-        return csr_of(graph, int(graph.x.shape[0]), self._csr_cache)
+        if self.training and self.maybe_edge_dropout is not noop and self.maybe_edge_dropout.dropout_prob > 0.0:
+            work = graph if not self._create_graph_copy else _LatentGraph(graph, graph.x, graph.edge_attr)
+            self.maybe_edge_dropout(work)
+            return work, build_csr(work.edge_index, int(work.x.shape[0]))
+        return graph, csr_of(graph, int(graph.x.shape[0]), self._csr_cache)
 
     def transform_to_features(self, graph):
         return unpack_features(graph, agent_node_type=self._node_type)
@@ -97,13 +106,20 @@ class MessagePassingBase(nn.Module):
         Returns ({node_type: x[N,L]}, {"edges": {edge_index, edge_attr[E,L]}}, {node_type: batch}) for
         output_type="features", None for "graph".  The caller's graph is only mutated when
         create_graph_copy=False (then x / edge_attr become the latent features, as in the reference)."""
-        csr = self.prepare(graph)
+        caller_graph = graph
+        graph, csr = self.prepare(graph)
         if self._output_type == "graph" and self._create_graph_copy:
             return None  # the reference computes on a private copy and returns noop(graph) == None
         desc = engine.make_desc(**self.desc_kwargs())
-        flat, packed = self._packed.get(desc, self.param_list())
-        node, edge, _ = engine.forward(desc, flat, packed, graph.x, graph.edge_attr, csr, want_node=True, want_edge=True)
+        params = self.param_list()
+        if engine.wants_grad(params):  # training step: autograd through amber_mpn_forward_train / amber_mpn_backward
+            node, edge, _ = engine.MpnFunction.apply(desc, self._packed, graph.x, graph.edge_attr, csr, None, None, True, True,
+                                                     *params)
+        else:
+            flat, packed = self._packed.get(desc, params)
+            node, edge, _ = engine.forward(desc, flat, packed, graph.x, graph.edge_attr, csr, want_node=True, want_edge=True)
         if not self._create_graph_copy:
+            graph = caller_graph
             graph.__setattr__("x", node)
             graph.__setattr__("edge_attr", edge)
         if self._output_type == "graph":

@@ -158,6 +158,13 @@ int amber_mpn_block(const AmberMpnDesc* desc, const float* params, const float* 
                     const int32_t* dst_sorted, float* x_latent, float* e_latent_sorted, void* workspace,
                     size_t workspace_bytes, void* stream);
 
+/* First-layer projections of the edge MLP of block `step` (the weight split of
+ * MessagePassingEdgeModule.forward, src/mpn/message_passing_modules.py:46-52: W0 [x_s | x_d | e] = W0s x_s + W0d x_d + W0e e):
+ * p_src[N,L] = W0[:, 0:L] x,  p_dst[N,L] = W0[:, L:2L] x + b0.  The block and forward entry points compute them
+ * internally; exposed for per-stage parity tests. */
+int amber_mpn_project(const AmberMpnDesc* desc, const float* params, const float* packed, int32_t step, int64_t num_nodes,
+                      const float* x_latent, float* p_src, float* p_dst, void* stream);
+
 /* SupervisedMPN head (src/algorithm/architecture/supervised_mpn.py:51-54; MLP mlp.py:60-95):
  * out_sizing[out_index[n]] = readout(decoder(x_latent[n])) for every n with out_index[n] >= 0
  * (out_index == NULL: identity).  out_index encodes x[mask_output]: the rank of n among kept nodes. */
@@ -190,6 +197,37 @@ int amber_mpn_forward_timed(const AmberMpnDesc* desc, const float* params, const
                             const int32_t* out_index, float* out_node, float* out_edge, float* out_sizing,
                             void* workspace, size_t workspace_bytes, void* stream, float* kernel_ms,
                             int32_t* kernel_launches);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Training (autograd through the path; the reference's training step: src/algorithm/core/amber.py:62-82 calls
+ * loss.backward() on the output of SupervisedMPN.forward).
+ *
+ * amber_mpn_forward_train = amber_mpn_forward that additionally keeps the block inputs of every step on a
+ * caller-owned TAPE (x_t[N,L], e_t[E,L] in CSR order, t = 0 .. num_steps * num_step_repeats;
+ * amber_mpn_tape_bytes).  amber_mpn_backward recomputes each module from its tape entry (activation checkpointing
+ * per block) and writes the gradient of every parameter, in the layout of `params`, to grad_params
+ * (amber_mpn_param_floats floats, overwritten).  Gradients arrive as any of
+ *   grad_sizing[N_m] (needs has_head), grad_node[N,L], grad_edge[E,L] (edge_index order); NULL = zero.
+ * Inputs (x, edge_attr) get no gradient: they are data, not parameters (nothing upstream of the MPN trains).
+ * rowptr_src / perm_src: the SOURCE-sorted order of the CSR positions, i.e. amber_mpn_csr_build applied to the
+ * edge list [dst_sorted ; src_sorted] (its rowptr and perm outputs) -- used for the deterministic per-source sums.
+ * Edge dropout (src/mpn/common/edge_dropout.py:24-25) happens before the call: the caller passes the kept edges.
+ * Built for: residual / layer_norm none or inner, linear or constant embeddings, decoder activations relu /
+ * leakyrelu / tanh without latent normalisation; everything else returns AMBER_ERR_UNSUPPORTED.
+ * ------------------------------------------------------------------------------------------------- */
+size_t amber_mpn_tape_bytes(const AmberMpnDesc* desc, int64_t num_nodes, int64_t num_edges);
+int amber_mpn_forward_train(const AmberMpnDesc* desc, const float* params, const float* packed, int64_t num_nodes,
+                            int64_t num_edges, const float* x, const float* edge_attr, const int32_t* rowptr,
+                            const int32_t* src_sorted, const int32_t* dst_sorted, const int32_t* perm,
+                            const int32_t* out_index, float* out_node, float* out_edge, float* out_sizing, void* tape,
+                            size_t tape_bytes, void* workspace, size_t workspace_bytes, void* stream);
+size_t amber_mpn_backward_workspace_bytes(const AmberMpnDesc* desc, int64_t num_nodes, int64_t num_edges);
+int amber_mpn_backward(const AmberMpnDesc* desc, const float* params, const float* packed, int64_t num_nodes,
+                       int64_t num_edges, const float* x, const float* edge_attr, const int32_t* rowptr,
+                       const int32_t* src_sorted, const int32_t* dst_sorted, const int32_t* perm,
+                       const int32_t* rowptr_src, const int32_t* perm_src, const int32_t* out_index,
+                       const float* grad_node, const float* grad_edge, const float* grad_sizing, void* tape,
+                       size_t tape_bytes, float* grad_params, void* workspace, size_t workspace_bytes, void* stream);
 
 int amber_mpn_abi_version(void);
 const char* amber_mpn_last_error(void);

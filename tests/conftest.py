@@ -31,6 +31,16 @@ def load_golden(name):
     return cfg, params, data
 
 
+def load_golden_grads(name):
+    """(grad_out, {state_dict name: reference gradient}) of a fixture that holds the reference's autograd gradients,
+    else None."""
+    z = np.load(os.path.join(GOLDEN_DIR, f"{name}.npz"), allow_pickle=False)
+    if "grad_out" not in z.files:
+        return None
+    grads = {k[len("grad/"):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("grad/")}
+    return torch.from_numpy(z["grad_out"]), grads
+
+
 def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
     """max |a - b| / max |b|: error relative to the output's scale (the tolerance form used throughout)."""
     if b.numel() == 0:

@@ -7,7 +7,10 @@ scatter_mean is restated in the stand-in, so that one link stays "parity unpinne
 
 Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
 Writes tests/golden/<case>.npz holding: the case config (JSON), the reference state_dict, the input graph
-and the reference outputs (node latents, edge latents, SupervisedMPN sizing output).
+and the reference outputs (node latents, edge latents, SupervisedMPN sizing output).  For the configurations the
+backward kernels take (TRAINABLE), additionally the reference's autograd gradients of sum(out * grad_out) with respect
+to every parameter ("grad/<state_dict name>"), computed in eval mode (edge dropout = identity, so they are
+deterministic) with gradient recording on.
 The GPU box never sees the reference; tests compare against these files.
 """
 import json
@@ -99,6 +102,10 @@ CASES = {
 }
 
 
+# cases inside what amber_mpn_backward is built for (include/amber_mpn.h)
+TRAINABLE = ("debug_L64_s2", "synth_L128_s2", "hier_L64_s3", "none_tanh_L32", "const_edge_L32", "const_node_L32", "repeat_L32_l3")
+
+
 def main():
     for name, (akw, kind, fn, fe, seed) in CASES.items():
         cfg = arch(**akw)
@@ -127,6 +134,15 @@ def main():
             "out_node": nodes["node"].numpy(), "out_edge": edges["edges"]["edge_attr"].numpy(),
             "out_sizing": out.numpy(),
         })
+        if name in TRAINABLE:
+            gen = torch.Generator().manual_seed(1000 + seed)
+            grad_out = torch.randn(out.shape, generator=gen)
+            model.zero_grad()
+            out_g = model(batch)  # REFERENCE forward with autograd
+            (out_g * grad_out).sum().backward()  # REFERENCE backward
+            blob["grad_out"] = grad_out.numpy()
+            for pname, p in model.named_parameters():
+                blob[f"grad/{pname}"] = p.grad.detach().numpy()
         path = os.path.join(HERE, f"{name}.npz")
         np.savez_compressed(path, **blob)
         print(f"{name}: N={g.x.shape[0]} E={g.edge_index.shape[1]} params={sum(p.numel() for p in model.parameters())} "
