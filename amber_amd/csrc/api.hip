@@ -573,7 +573,7 @@ BwdWorkspace carve_bwd(const AmberMpnDesc& d, int64_t N, int64_t E, void* base) 
   }
   w.gpart = take(align256(sizeof(float) * kWgradMaxChunks * L * L));
   w.cpart = take(align256(sizeof(float) * kWgradMaxChunks * L));
-  w.lnpart = take(align256(sizeof(float) * kBwdMaxBlocks * 4 * 2 * L));
+  w.lnpart = take(align256(sizeof(float) * kBwdMaxBlocks * 2 * L));
   w.epart = take(align256(sizeof(float) * kWgradMaxChunks * L * 65));
   w.mat_floats = L * L + kPackedHeader;
   w.mats = take(align256(sizeof(float) * kBwdMats * w.mat_floats));
@@ -610,7 +610,7 @@ int backward_impl(const AmberMpnDesc* desc, const float* params, const float* pa
     else
       HIP_TRY(hipMemsetAsync(w.dE, 0, sizeof(float) * EL, s), "clear dE");
   }
-  const int gn = chain_bwd_grid(N) * 4, ge = chain_bwd_grid(E) * 4;
+  const int gn = chain_bwd_grid(N), ge = chain_bwd_grid(E);  // partial column sums: one per workgroup
 
   // ---- SupervisedMPN head: readout(decoder(x_T[mask])) ----
   if (d.has_head && grad_sizing) {

@@ -23,6 +23,28 @@ namespace amber {
 // ---------------------------------------------------------------------------------------------------
 // wave-local tile helpers (no workgroup barrier: every wave walks its own tiles)
 // ---------------------------------------------------------------------------------------------------
+// tile_gemm with a bounded weight prefetch: left alone, the scheduler hoists the loads of ALL k-steps' weight tiles
+// (L = 128: 256 registers) above the first MFMA; a scheduling barrier every other k-step keeps two steps in flight.
+template <int L>
+DEVINL void tile_gemm_lean(Tile<L>& acc, const float* __restrict__ wpacked, const Tile<L>& in, int lane) {
+  constexpr int NFB = L / 32, NJ = L / 8;
+  const f32x4* __restrict__ w = reinterpret_cast<const f32x4*>(wpacked) + lane;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    f32x4 wf[NFB];
+#pragma unroll
+    for (int fb = 0; fb < NFB; ++fb) wf[fb] = w[(j * NFB + fb) * 64];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const float b = in.a[j >> 2][(j & 3) * 4 + t];
+#pragma unroll
+      for (int fb = 0; fb < NFB; ++fb) acc.a[fb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[fb][t], b, acc.a[fb], 0, 0, 0);
+    }
+#ifdef AMBER_BWD_SCHED_BARRIER
+    if ((j & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+#endif
+  }
+}
 template <int L>
 DEVINL void tile_store_w(float* stage, const Tile<L>& t, float* __restrict__ out, int64_t row0, int nvalid, int lane) {
   wave_sync();
@@ -132,14 +154,13 @@ DEVINL void wave_global_handover() {
 // then a_l = act(W_l a_{l-1} + b_l), r = a_last (+ rin), y = LayerNorm(r) (inner modes).
 // ---------------------------------------------------------------------------------------------------
 template <int L>
-__global__ __launch_bounds__(kBlock) void chain_bwd_kernel(const ChainBwdArgs a, const int64_t ntiles) {
+__global__ __launch_bounds__(kBlock, L <= 64 ? 2 : 1) void chain_bwd_kernel(const ChainBwdArgs a, const int64_t ntiles) {
   __shared__ __attribute__((aligned(16))) float stage_all[kWavesPerBlock * stage_floats<L>()];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int c = lane & 31, h = lane >> 5;
+  const int lane0 = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float* stage = stage_all + wave * stage_floats<L>();
   constexpr int FPL = (L + 63) / 64;
-  const bool active = lane * FPL < L;
-  const int fo = active ? lane * FPL : 0;
+  const bool active = lane0 * FPL < L;
+  const int fo = active ? lane0 * FPL : 0;
   float ps0[FPL], ps1[FPL];
 #pragma unroll
   for (int q = 0; q < FPL; ++q) ps0[q] = ps1[q] = 0.f;
@@ -147,42 +168,53 @@ __global__ __launch_bounds__(kBlock) void chain_bwd_kernel(const ChainBwdArgs a,
   const int64_t gw = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave;
   const int64_t G = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
   for (int64_t tile = gw; tile < ntiles; tile += G) {
+    // The lane id is re-derived from an opaque copy in every iteration: with a loop-invariant lane id the weight tiles,
+    // biases and LayerNorm parameters are loop-invariant loads, and hoisted out of the tile loop they occupy (and spill)
+    // hundreds of registers.
+    int lane = lane0;
+#ifndef AMBER_BWD_ALLOW_HOIST
+    asm volatile("" : "+v"(lane));
+#endif
+    const int c = lane & 31, h = lane >> 5;
     const int64_t p0 = tile * kTile;
     const int nvalid = (a.rows - p0) < kTile ? static_cast<int>(a.rows - p0) : kTile;
     int64_t p = p0 + c;
     if (p > a.rows - 1) p = a.rows - 1;  // rows beyond the end repeat the last row; their gradient is zeroed below
     const bool rowok = c < nvalid;
 
-    // ---- recompute the forward chain ----
-    Tile<L> rin;
-    tile_load_row<L>(rin, a.rin, p, h);
+    // ---- recompute the forward chain (tiles that are needed again later are re-read, not kept: registers) ----
     Tile<L> cur;
     int d = 0;
-    if (a.nl == 0) {
-      cur = rin;
-    } else {
-      if (a.mode == AMBER_BWD_EDGE) {
-        const int s = a.src[p];
-        d = a.dst[p];
-        tile_load_row<L>(cur, a.Ps, s, h);
-        tile_add_row<L>(cur, a.Pd, d, h);
-        tile_gemm<L>(cur, a.w_in, rin, lane);
+    if (a.mode == AMBER_BWD_EDGE) d = a.dst[p];
+    {
+      Tile<L> rin;
+      tile_load_row<L>(rin, a.rin, p, h);
+      if (a.nl == 0) {
+        cur = rin;
       } else {
-        tile_load_vec<L>(cur, a.b0, h);
-        tile_gemm<L>(cur, a.w_in, rin, lane);
-        if (a.mode == AMBER_BWD_NODE) {
-          Tile<L> mt;
-          tile_load_row<L>(mt, a.m, p, h);
-          tile_gemm<L>(cur, a.w_m, mt, lane);
+        if (a.mode == AMBER_BWD_EDGE) {
+          const int s = a.src[p];
+          tile_load_row<L>(cur, a.Ps, s, h);
+          tile_add_row<L>(cur, a.Pd, d, h);
+          tile_gemm_lean<L>(cur, a.w_in, rin, lane);
+        } else {
+          tile_load_vec<L>(cur, a.b0, h);
+          tile_gemm_lean<L>(cur, a.w_in, rin, lane);
+          if (a.mode == AMBER_BWD_NODE) {
+            tile_load_row<L>(rin, a.m, p, h);
+            tile_gemm_lean<L>(cur, a.w_m, rin, lane);
+          }
         }
       }
+    }
+    if (a.nl > 0) {
       tile_act_w<L>(cur, a.act, stage, lane);
 #pragma unroll 1
       for (int l = 1; l < a.nl; ++l) {
         tile_store_w<L>(stage, cur, a.A[l - 1], p0, nvalid, lane);  // input of layer l: needed by dW_l and by act' below
         Tile<L> nxt;
         tile_load_vec<L>(nxt, a.layers[l].b, h);
-        tile_gemm<L>(nxt, a.layers[l].w, cur, lane);
+        tile_gemm_lean<L>(nxt, a.layers[l].w, cur, lane);
         tile_act_w<L>(nxt, a.act, stage, lane);
         cur = nxt;
       }
@@ -190,7 +222,6 @@ __global__ __launch_bounds__(kBlock) void chain_bwd_kernel(const ChainBwdArgs a,
     // ---- gradient arriving at the module's output ----
     Tile<L> dr;
     if (a.mode == AMBER_BWD_EDGE) {
-      if (a.nl == 0) d = a.dst[p];
       tile_load_row<L>(dr, a.dio, p, h);
       const float inv = 1.0f / static_cast<float>(max(a.rowptr[d + 1] - a.rowptr[d], 1));  // scatter_mean's divisor
       const f32x4* pm = reinterpret_cast<const f32x4*>(a.dm_in + static_cast<int64_t>(d) * L) + h;
@@ -202,15 +233,14 @@ __global__ __launch_bounds__(kBlock) void chain_bwd_kernel(const ChainBwdArgs a,
       const int64_t oi = a.out_index ? static_cast<int64_t>(a.out_index[p]) : p;
       const float dscal = (rowok && oi >= 0) ? a.dout[oi] : 0.f;
       // readout gradients: d wr = sum_rows dout * a_last, d br = sum_rows dout
-      Tile<L> t;
 #pragma unroll
-      for (int fb = 0; fb < L / 32; ++fb) t.a[fb] = cur.a[fb] * dscal;
-      tile_colsum_acc<L, FPL>(stage, t, ps0, active, fo, lane);
+      for (int fb = 0; fb < L / 32; ++fb) dr.a[fb] = cur.a[fb] * dscal;
+      tile_colsum_acc<L, FPL>(stage, dr, ps0, active, fo, lane);
 #pragma unroll
       for (int fb = 0; fb < L / 32; ++fb)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) t.a[fb][i] = dscal;
-      tile_colsum_acc<L, FPL>(stage, t, ps1, active, fo, lane);
+        for (int i = 0; i < 16; ++i) dr.a[fb][i] = dscal;
+      tile_colsum_acc<L, FPL>(stage, dr, ps1, active, fo, lane);
       tile_load_vec<L>(dr, a.wr, h);
 #pragma unroll
       for (int fb = 0; fb < L / 32; ++fb) dr.a[fb] = dr.a[fb] * dscal;
@@ -219,149 +249,262 @@ __global__ __launch_bounds__(kBlock) void chain_bwd_kernel(const ChainBwdArgs a,
     // ---- LayerNorm backward (statistics recomputed) ----
     if (a.layer_norm == AMBER_MODE_INNER) {
       Tile<L> xh = cur;
-      if (a.residual == AMBER_MODE_INNER) tile_add<L>(xh, rin);
+      if (a.residual == AMBER_MODE_INNER) tile_add_row<L>(xh, a.rin, p, h);
       const float rstd = tile_ln_xhat<L>(xh, a.eps);
+      tile_colsum_acc<L, FPL>(stage, dr, ps1, active, fo, lane);  // d beta
+      // g = gamma * dy (in place), row means of g and g * xhat
       {
-        Tile<L> t;
+        const f32x4* gp = reinterpret_cast<const f32x4*>(a.gamma) + h;
+        // d gamma: column sums of dy * xhat, staged without a tile of its own
+        wave_sync();
+        {
+          f32x4* sp = reinterpret_cast<f32x4*>(stage + c * stage_stride<L>()) + h;
 #pragma unroll
-        for (int fb = 0; fb < L / 32; ++fb) t.a[fb] = dr.a[fb] * xh.a[fb];
-        tile_colsum_acc<L, FPL>(stage, t, ps0, active, fo, lane);  // d gamma
-        tile_colsum_acc<L, FPL>(stage, dr, ps1, active, fo, lane); // d beta
+          for (int j = 0; j < L / 8; ++j) sp[2 * j] = tile_get_chunk<L>(dr, j) * tile_get_chunk<L>(xh, j);
+        }
+        wave_sync();
+        if (active) {
+          for (int r = 0; r < kTile; ++r)
+#pragma unroll
+            for (int q = 0; q < FPL; ++q) ps0[q] += stage[r * stage_stride<L>() + fo + q];
+        }
+#pragma unroll
+        for (int j = 0; j < L / 8; ++j) tile_set_chunk<L>(dr, j, tile_get_chunk<L>(dr, j) * gp[2 * j]);
       }
-      Tile<L> g;
-      tile_load_vec<L>(g, a.gamma, h);
+      const float m1 = tile_row_sum<L>(dr) * (1.0f / L);
+      const float m2 = tile_row_dot<L>(dr, xh) * (1.0f / L);
 #pragma unroll
-      for (int fb = 0; fb < L / 32; ++fb) g.a[fb] = g.a[fb] * dr.a[fb];
-      const float m1 = tile_row_sum<L>(g) * (1.0f / L);
-      const float m2 = tile_row_dot<L>(g, xh) * (1.0f / L);
-#pragma unroll
-      for (int fb = 0; fb < L / 32; ++fb) dr.a[fb] = (g.a[fb] - m1 - xh.a[fb] * m2) * rstd;
+      for (int fb = 0; fb < L / 32; ++fb) dr.a[fb] = (dr.a[fb] - m1 - xh.a[fb] * m2) * rstd;
     }
     // ---- chain rule through the layers, last to first ----
-    Tile<L> din;
-    if (a.nl == 0) {
-      din = dr;
-    } else {
-      Tile<L> dcur = dr;
-      if (a.nl > 1) wave_global_handover();  // the A[l] rows stored above are re-read by other lanes
+    if (a.nl > 0) {
+      const bool keep = a.residual == AMBER_MODE_INNER;
+      if (keep) tile_store_w<L>(stage, dr, a.dio, p0, nvalid, lane);  // parked in memory until it joins the input gradient
+      if (a.nl > 1 || keep) wave_global_handover();  // rows stored above are re-read by other lanes of this wave
 #pragma unroll 1
       for (int l = a.nl - 1; l >= 1; --l) {
         if (l != a.nl - 1) tile_load_row<L>(cur, a.A[l], p, h);
-        tile_mul_dact<L>(dcur, cur, a.act);
-        tile_store_w<L>(stage, dcur, a.DH[l], p0, nvalid, lane);
+        tile_mul_dact<L>(dr, cur, a.act);
+        tile_store_w<L>(stage, dr, a.DH[l], p0, nvalid, lane);
         Tile<L> nd;
         tile_zero<L>(nd);
-        tile_gemm<L>(nd, a.wT[l], dcur, lane);
-        dcur = nd;
+        tile_gemm_lean<L>(nd, a.wT[l], dr, lane);
+        dr = nd;
       }
       if (a.nl > 1) tile_load_row<L>(cur, a.A[0], p, h);
-      tile_mul_dact<L>(dcur, cur, a.act);
-      tile_store_w<L>(stage, dcur, a.DH[0], p0, nvalid, lane);
-      if (a.residual == AMBER_MODE_INNER)
-        din = dr;
-      else
-        tile_zero<L>(din);
-      tile_gemm<L>(din, a.wT_in, dcur, lane);
+      tile_mul_dact<L>(dr, cur, a.act);
+      tile_store_w<L>(stage, dr, a.DH[0], p0, nvalid, lane);
       if (a.mode == AMBER_BWD_NODE) {
-        Tile<L> dm;
-        tile_zero<L>(dm);
-        tile_gemm<L>(dm, a.wT_m, dcur, lane);
-        tile_store_w<L>(stage, dm, a.dm_out, p0, nvalid, lane);
+        tile_zero<L>(cur);
+        tile_gemm_lean<L>(cur, a.wT_m, dr, lane);
+        tile_store_w<L>(stage, cur, a.dm_out, p0, nvalid, lane);
+      }
+      // gradient at the first layer's streamed input (+ the parked residual term; head: + what arrived at the latents)
+      if (keep || a.mode == AMBER_BWD_HEAD)
+        tile_load_row<L>(cur, a.dio, p, h);
+      else
+        tile_zero<L>(cur);
+      tile_gemm_lean<L>(cur, a.wT_in, dr, lane);
+      tile_store_w<L>(stage, cur, a.dio, p0, nvalid, lane);
+    } else {
+      if (a.mode == AMBER_BWD_HEAD) tile_add_row<L>(dr, a.dio, p, h);
+      tile_store_w<L>(stage, dr, a.dio, p0, nvalid, lane);
+    }
+  }
+  // partial column sums: the block's four waves are added in wave order through LDS, one partial per block
+  if (a.part) {
+    __syncthreads();  // every wave is past its last tile: the stages are free
+    float* red = stage_all;  // [wave][2][L]
+    if (active) {
+#pragma unroll
+      for (int q = 0; q < FPL; ++q) {
+        red[(wave * 2 + 0) * L + fo + q] = ps0[q];
+        red[(wave * 2 + 1) * L + fo + q] = ps1[q];
       }
     }
-    if (a.mode == AMBER_BWD_HEAD) tile_add_row<L>(din, a.dio, p, h);  // joins a gradient that arrived at the node latents
-    tile_store_w<L>(stage, din, a.dio, p0, nvalid, lane);
-  }
-  if (a.part && active) {
-    float* pp = a.part + gw * 2 * L;
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * L; i += kBlock) {
+      float sum = red[i];
 #pragma unroll
-    for (int q = 0; q < FPL; ++q) {
-      pp[fo + q] = ps0[q];
-      pp[L + fo + q] = ps1[q];
+      for (int w = 1; w < kWavesPerBlock; ++w) sum += red[w * 2 * L + i];
+      a.part[static_cast<int64_t>(blockIdx.x) * 2 * L + i] = sum;
     }
   }
 }
 
-// out0[f] += sum_g part[g][0][f] (f < n0), out1[f] += sum_g part[g][1][f] (f < n1), in g order
-__global__ void colpart_reduce_kernel(const float* __restrict__ part, int G, int L, float* __restrict__ out0, int n0,
-                                      float* __restrict__ out1, int n1) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 2 * L) return;
+// out0[f] += sum_g part[g][0][f] (f < n0), out1[f] += sum_g part[g][1][f] (f < n1): one wave per output, lane j adds
+// the partials g = j, j + 64, ... in order and the lanes are combined by a fixed butterfly (deterministic)
+__global__ __launch_bounds__(64) void colpart_reduce_kernel(const float* __restrict__ part, int G, int L, float* __restrict__ out0, int n0,
+                                                            float* __restrict__ out1, int n1) {
+  const int i = blockIdx.x;  // output (k, f)
   const int k = i / L, f = i % L;
   float* out = k == 0 ? out0 : out1;
   if (!out || f >= (k == 0 ? n0 : n1)) return;
   float s = 0.f;
-  for (int g = 0; g < G; ++g) s += part[(static_cast<int64_t>(g) * 2 + k) * L + f];
-  out[f] += s;
+  for (int g = threadIdx.x; g < G; g += 64) s += part[(static_cast<int64_t>(g) * 2 + k) * L + f];
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+  if (threadIdx.x == 0) out[f] += s;
 }
 
 // ---------------------------------------------------------------------------------------------------
-// weight gradient: P[g] = A[rows of chunk g]^T B[rows of chunk g]  (A, B: [M, L] row-major), the rows are the
-// contraction dimension: v_mfma_f32_32x32x2_f32 with two rows per instruction, both operands loaded coalesced
-// straight from memory (lane (h, c): row r + h, column 32 blk + c).  One wave per block of 32 output features.
+// weight gradient: P[g] = A[rows of chunk g]^T B[rows of chunk g]  (A, B: [M, L] row-major).  The rows are the
+// contraction dimension: v_mfma_f32_32x32x2_f32 takes two rows per instruction, and both operands come straight from
+// memory, coalesced: lane (h, c) loads row r + h, features VEC c .. VEC c + VEC - 1 (VEC = L / 32 floats, one vector
+// load of B per row pair), and MFMA (ta, tb) pairs element ta of the A vector with element tb of the B vector, i.e. the
+// 32 x 32 tile of output features {VEC m + ta} x input features {VEC n + tb} - a relabelling of the tiles, undone by
+// the store.  A workgroup is 8 waves: GROUPS = VEC / TA groups split the A elements (a wave keeps TA x VEC tiles, 64
+// registers at L = 128 / 64) and S = 8 / GROUPS row slices split the chunk's rows; the slices are added in slice order
+// through LDS, one partial product per workgroup.
 // ---------------------------------------------------------------------------------------------------
+template <int N>
+struct VecOf {
+  typedef float type __attribute__((ext_vector_type(N)));
+};
+template <>
+struct VecOf<1> {
+  typedef float type;
+};
 template <int L>
-__global__ __launch_bounds__(64 * (L / 32)) void wgrad_kernel(const float* __restrict__ A, const float* __restrict__ B, int64_t M,
-                                                              int64_t chunk, float* __restrict__ part, float* __restrict__ cpart) {
-  constexpr int NFB = L / 32, U = 8;
-  const int lane = threadIdx.x & 63, ob = threadIdx.x >> 6;
+struct WgradCfg {
+  static constexpr int VEC = L / 32;
+  static constexpr int TA = L == 64 ? 2 : 1;
+  static constexpr int GROUPS = VEC / TA;
+  static constexpr int S = 8 / GROUPS;
+  static constexpr int TILE_FLOATS = TA * VEC * 16 * 64;  // one wave's accumulators
+  static constexpr size_t lds_bytes() { return sizeof(float) * (static_cast<size_t>(S - 1) * GROUPS * (TILE_FLOATS + TA * 32)); }
+};
+
+template <int L>
+__global__ __launch_bounds__(512) void wgrad_kernel(const float* __restrict__ A, const float* __restrict__ B, int64_t M, int64_t chunk,
+                                                    float* __restrict__ part, float* __restrict__ cpart) {
+  using C = WgradCfg<L>;
+  constexpr int VEC = C::VEC, TA = C::TA, GROUPS = C::GROUPS, S = C::S, U = 8;
+  typedef typename VecOf<VEC>::type vecf;
+  typedef typename VecOf<TA>::type veca;
+  extern __shared__ __attribute__((aligned(16))) float red[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int c = lane & 31, h = lane >> 5;
+  const int grp = wave % GROUPS, slice = wave / GROUPS;
   const int64_t r0 = static_cast<int64_t>(blockIdx.x) * chunk;
   const int64_t r1 = r0 + chunk < M ? r0 + chunk : M;
-  f32x16 acc[NFB];
+  const int64_t sub = ((chunk + S - 1) / S + 1) & ~static_cast<int64_t>(1);  // rows per slice, even
+  const int64_t rs0 = r0 + slice * sub;
+  const int64_t rs1 = rs0 + sub < r1 ? rs0 + sub : r1;
+  f32x16 acc[TA][VEC];
 #pragma unroll
-  for (int j = 0; j < NFB; ++j)
+  for (int ta = 0; ta < TA; ++ta)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
-  float cs = 0.f;
-  for (int64_t r = r0; r < r1; r += 2 * U) {
-    float av[U], bv[U][NFB];
+    for (int tb = 0; tb < VEC; ++tb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[ta][tb][i] = 0.f;
+  float cs[TA];
+#pragma unroll
+  for (int ta = 0; ta < TA; ++ta) cs[ta] = 0.f;
+  for (int64_t r = rs0; r < rs1; r += 2 * U) {
+    veca av[U];
+    vecf bv[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int64_t rr = r + 2 * u + h;
-      const bool ok = rr < r1;
-      const int64_t rc = ok ? rr : r0;
-      const float x = A[rc * L + 32 * ob + c];
-      av[u] = ok ? x : 0.f;
-#pragma unroll
-      for (int j = 0; j < NFB; ++j) {
-        const float y = B[rc * L + 32 * j + c];
-        bv[u][j] = ok ? y : 0.f;
+      const bool ok = rr < rs1;
+      const int64_t rc = ok ? rr : rs0;
+      veca x = *reinterpret_cast<const veca*>(A + rc * L + VEC * c + TA * grp);
+      vecf y = *reinterpret_cast<const vecf*>(B + rc * L + VEC * c);
+      if (!ok) {
+        x = x * 0.f;
+        y = y * 0.f;
       }
+      av[u] = x;
+      bv[u] = y;
     }
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      cs += av[u];
+    for (int u = 0; u < U; ++u)
 #pragma unroll
-      for (int j = 0; j < NFB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u][j], acc[j], 0, 0, 0);
+      for (int ta = 0; ta < TA; ++ta) {
+        float xa;
+        if constexpr (TA == 1) xa = av[u]; else xa = av[u][ta];
+        cs[ta] += xa;
+#pragma unroll
+        for (int tb = 0; tb < VEC; ++tb) {
+          float yb;
+          if constexpr (VEC == 1) yb = bv[u]; else yb = bv[u][tb];
+          acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa, yb, acc[ta][tb], 0, 0, 0);
+        }
+      }
+  }
+#pragma unroll
+  for (int ta = 0; ta < TA; ++ta) cs[ta] += __shfl_xor(cs[ta], 32);
+  // ---- add the row slices in slice order ----
+  float* cred = red + static_cast<size_t>(S - 1) * GROUPS * C::TILE_FLOATS;
+  if (slice > 0) {
+    float* mine = red + static_cast<size_t>((slice - 1) * GROUPS + grp) * C::TILE_FLOATS;
+#pragma unroll
+    for (int ta = 0; ta < TA; ++ta)
+#pragma unroll
+      for (int tb = 0; tb < VEC; ++tb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mine[((ta * VEC + tb) * 16 + i) * 64 + lane] = acc[ta][tb][i];
+    if (h == 0) {
+#pragma unroll
+      for (int ta = 0; ta < TA; ++ta) cred[((slice - 1) * GROUPS + grp) * TA * 32 + ta * 32 + c] = cs[ta];
     }
   }
+  __syncthreads();
+  if (slice > 0) return;
+  for (int sl = 1; sl < S; ++sl) {
+    const float* other = red + static_cast<size_t>((sl - 1) * GROUPS + grp) * C::TILE_FLOATS;
+#pragma unroll
+    for (int ta = 0; ta < TA; ++ta)
+#pragma unroll
+      for (int tb = 0; tb < VEC; ++tb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[ta][tb][i] += other[((ta * VEC + tb) * 16 + i) * 64 + lane];
+#pragma unroll
+    for (int ta = 0; ta < TA; ++ta) cs[ta] += cred[((sl - 1) * GROUPS + grp) * TA * 32 + ta * 32 + c];
+  }
+  // ---- store: register i of tile (ta, tb) is output feature VEC m + TA grp + ta, input feature VEC c + tb ----
   float* P = part + static_cast<int64_t>(blockIdx.x) * L * L;
 #pragma unroll
-  for (int j = 0; j < NFB; ++j)
+  for (int ta = 0; ta < TA; ++ta)
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int m = (i & 3) + 8 * (i >> 2) + 4 * h;
-      P[(32 * ob + m) * L + 32 * j + c] = acc[j][i];
+      vecf v;
+#pragma unroll
+      for (int tb = 0; tb < VEC; ++tb) {
+        if constexpr (VEC == 1) v = acc[ta][tb][i]; else v[tb] = acc[ta][tb][i];
+      }
+      *reinterpret_cast<vecf*>(P + (VEC * m + TA * grp + ta) * L + VEC * c) = v;
     }
-  if (cpart) {
-    cs += __shfl_xor(cs, 32);
-    if (h == 0) cpart[static_cast<int64_t>(blockIdx.x) * L + 32 * ob + c] = cs;
+  if (cpart && h == 0) {
+#pragma unroll
+    for (int ta = 0; ta < TA; ++ta) cpart[static_cast<int64_t>(blockIdx.x) * L + VEC * c + TA * grp + ta] = cs[ta];
   }
 }
-// dW[o][col0 + k] += sum_g part[g][o][k];  db[o] += sum_g cpart[g][o]   (g ascending: deterministic)
-__global__ void wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ cpart, int G, int L,
-                                    float* __restrict__ dW, int ld, int col0, float* __restrict__ db) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < L * L) {
-    float s = 0.f;
-    for (int g = 0; g < G; ++g) s += part[static_cast<int64_t>(g) * L * L + i];
-    dW[static_cast<int64_t>(i / L) * ld + col0 + (i % L)] += s;
-  } else if (i < L * L + L && db && cpart) {
-    const int o = i - L * L;
-    float s = 0.f;
-    for (int g = 0; g < G; ++g) s += cpart[static_cast<int64_t>(g) * L + o];
-    db[o] += s;
+// dW[o][col0 + k] += sum_g part[g][o][k];  db[o] += sum_g cpart[g][o].  A workgroup takes 64 consecutive outputs and
+// four interleaved subsequences of g, combined in a fixed order (deterministic).
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ cpart, int G, int L,
+                                                           float* __restrict__ dW, int ld, int col0, float* __restrict__ db) {
+  __shared__ float sm[4][64];
+  const int i = blockIdx.x * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
+  const int LL = L * L;
+  const bool is_w = i < LL, is_b = !is_w && i < LL + L && db && cpart;
+  float s = 0.f;
+  if (is_w) {
+    for (int g = sl; g < G; g += 4) s += part[static_cast<int64_t>(g) * LL + i];
+  } else if (is_b) {
+    for (int g = sl; g < G; g += 4) s += cpart[static_cast<int64_t>(g) * L + (i - LL)];
+  }
+  sm[sl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (sl == 0) {
+    const int t = threadIdx.x;
+    const float tot = ((sm[0][t] + sm[1][t]) + sm[2][t]) + sm[3][t];
+    if (is_w)
+      dW[static_cast<int64_t>(i / L) * ld + col0 + (i % L)] += tot;
+    else if (is_b)
+      db[i - LL] += tot;
   }
 }
 
@@ -489,17 +632,14 @@ hipError_t launch_chain_bwd(int L, const ChainBwdArgs& a, hipStream_t s) {
   }
 }
 hipError_t launch_colpart_reduce(const float* part, int G, int L, float* out0, int n0, float* out1, int n1, hipStream_t s) {
-  hipLaunchKernelGGL(colpart_reduce_kernel, dim3(cdiv(2 * L, 256)), dim3(256), 0, s, part, G, L, out0, n0, out1, n1);
+  hipLaunchKernelGGL(colpart_reduce_kernel, dim3(2 * L), dim3(64), 0, s, part, G, L, out0, n0, out1, n1);
   return hipGetLastError();
 }
 
 int wgrad_chunks(int64_t M, int64_t* chunk_out) {
-  int64_t chunk = 512;
+  int64_t chunk = cdiv(cdiv(M, kWgradMaxChunks), 16) * 16;
+  if (chunk < 256) chunk = 256;
   int64_t G = cdiv(M, chunk);
-  if (G > kWgradMaxChunks) {
-    chunk = cdiv(cdiv(M, kWgradMaxChunks), 16) * 16;
-    G = cdiv(M, chunk);
-  }
   if (G < 1) G = 1;
   if (chunk_out) *chunk_out = chunk;
   return static_cast<int>(G);
@@ -509,10 +649,14 @@ static hipError_t launch_wgrad_t(const float* A, const float* B, int64_t M, floa
                                  float* cpart, hipStream_t s) {
   int64_t chunk = 0;
   const int G = wgrad_chunks(M, &chunk);
-  hipLaunchKernelGGL(wgrad_kernel<L>, dim3(G), dim3(64 * (L / 32)), 0, s, A, B, M, chunk, part, db ? cpart : nullptr);
-  hipError_t e = hipGetLastError();
+  const size_t lds = WgradCfg<L>::lds_bytes();
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<L>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     static_cast<int>(lds));
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(L * L + L, 256)), dim3(256), 0, s, part, db ? cpart : nullptr, G, L, dW, ld, col0, db);
+  hipLaunchKernelGGL(wgrad_kernel<L>, dim3(G), dim3(512), lds, s, A, B, M, chunk, part, db ? cpart : nullptr);
+  e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(L * L + L, 64)), dim3(256), 0, s, part, db ? cpart : nullptr, G, L, dW, ld, col0, db);
   return hipGetLastError();
 }
 hipError_t launch_wgrad(int L, const float* A, const float* B, int64_t M, float* dW, int ld, int col0, float* db, float* part,

@@ -127,7 +127,7 @@ hipError_t launch_permute_rows(const float* in, const int32_t* perm, int64_t row
 
 // ---- backward (training), mpn_bwd.hip ----
 enum { AMBER_BWD_EDGE = 0, AMBER_BWD_NODE = 1, AMBER_BWD_HEAD = 2 };
-constexpr int kBwdMaxBlocks = 1024;    // persistent grid of the chain kernel (4 waves a block)
+constexpr int kBwdMaxBlocks = 512;     // persistent grid of the chain kernel (4 waves a block, one partial per block)
 constexpr int kWgradMaxChunks = 512;   // split-K chunks of a weight-gradient product
 // Recompute + chain rule of one module on 32-row tiles (see chain_bwd_kernel).  All matrices in the exact fp32 operand
 // order (launch_pack / launch_pack_t).

@@ -38,17 +38,27 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--graphs", type=int, default=100, help="graphs per batch (100 = BASELINE config 5)")
-    ap.add_argument("--nx", type=int, default=120)
-    ap.add_argument("--ny", type=int, default=120)
-    ap.add_argument("--latent", type=int, default=128)
-    ap.add_argument("--mp-steps", type=int, default=10)
+    ap.add_argument("--graphs", type=int, default=None, help="graphs per batch (default 100 = BASELINE config 5; --train: 3)")
+    ap.add_argument("--nx", type=int, default=None, help="grid vertices per side (default 120; --train: 144)")
+    ap.add_argument("--ny", type=int, default=None)
+    ap.add_argument("--latent", type=int, default=None, help="default 128 (--train: 64)")
+    ap.add_argument("--mp-steps", type=int, default=None, help="default 10 (--train: 20)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--precision", choices=["fp32", "f16x2", "f16"], default=None,
                     help="MLP contraction precision (default f16x2: fp32-grade, 1e-5; f16: reduced, 1e-2; fp32: exact fp32 MFMA)")
+    ap.add_argument("--train", action="store_true",
+                    help="secondary benchmark: one training step (forward with tape + backward + gradient all-reduce) on a "
+                         "BASELINE config 3 shaped batch (airfoil: 3 graphs of ~20.7k nodes / 144k edges, latent 64, 20 MP steps) "
+                         "unless --graphs/--nx/--ny/--latent/--mp-steps are given")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-graphs", type=int, default=10, help="graphs in the CPU-baseline sample (10 = 1M edges)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    defaults = dict(graphs=3, nx=144, ny=144, latent=64, mp_steps=20) if args.train else \
+        dict(graphs=100, nx=120, ny=120, latent=128, mp_steps=10)
+    for k, v in defaults.items():
+        if getattr(args, k) is None:
+            setattr(args, k, v)
+    return args
 
 
 def cpu_baseline(cfg, state_dict, args):
@@ -69,10 +79,74 @@ def cpu_baseline(cfg, state_dict, args):
             "sample": f"{args.cpu_graphs} of the {args.nx}x{args.ny} graphs (E={e}), one forward, {dt:.1f} s, torch CPU fp32"}
 
 
+def train_bench(args):
+    """Secondary metric (not BASELINE's headline): training-step throughput, edges/s of forward + backward."""
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=dev)
+    torch.manual_seed(0)
+    cfg = default_architecture(latent_dimension=args.latent, num_steps=args.mp_steps)
+    model = SupervisedMPN(cfg, syn.GraphBatch(x=torch.zeros(1, 4), edge_attr=torch.zeros(1, 2))).to(dev).train()
+    g = syn.grid_batch(num_graphs=args.graphs, nx=args.nx, ny=args.ny, seed=1234 + rank).to(dev)
+    n, e = int(g.x.shape[0]), int(g.edge_index.shape[1])
+    g.amber_csr = csr_mod.build_csr(g.edge_index, n)
+    target = torch.randn(n, 1, device=dev)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = torch.nn.functional.mse_loss(model(g), target)
+        loss.backward()  # gradient all-reduce (RCCL, one flat buffer) happens inside when world > 1
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    assert torch.isfinite(loss)
+    edges_done = torch.tensor([float(e) * args.steps], device=dev, dtype=torch.float64)
+    t_max = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if dist is not None:
+        dist.all_reduce(edges_done, op=dist.ReduceOp.SUM)
+        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        t = float(t_max.item())
+        print(json.dumps({
+            "metric": "mpn_train_step_edges_per_sec", "value": float(edges_done.item()) / t, "unit": "edges/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": t / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "precision": engine.default_precision, "data": "synthetic",
+            "config": {"workload": f"training step (forward with tape, backward, Adam) on {args.graphs} triangulated {args.nx}x{args.ny} "
+                                   f"grids per GPU, N={n} E={e}, latent {args.latent}, {args.mp_steps} MP steps, edge_dropout 0 "
+                                   f"(BASELINE config 3 shape by default)",
+                       "parallelism": f"graph-wise dp{world}, one gradient all-reduce per step"}}), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     if args.precision:
         engine.default_precision = args.precision
+    if args.train:
+        return train_bench(args)
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))

@@ -229,9 +229,9 @@ def test_errors_mirror_the_reference(gpu_device):
     cpu_graph = syn.grid_batch(num_graphs=1, nx=5, ny=5)
     with pytest.raises(RuntimeError, match="no CPU path"):
         mpn(cpu_graph)
-    mpn.train()
-    with pytest.raises(NotImplementedError):
-        mpn(syn.grid_batch(num_graphs=1, nx=5, ny=5).to(gpu_device))
+    mpn.train()  # training mode runs the autograd path (tests/test_gpu_training.py): latents carry a graph
+    nodes, edges, _ = mpn(syn.grid_batch(num_graphs=1, nx=5, ny=5).to(gpu_device))
+    assert nodes["node"].requires_grad and edges["edges"]["edge_attr"].requires_grad
     with pytest.raises(ValueError, match="Unknown activation function"):
         get_mpn(in_node_features=4, in_edge_features=2, latent_dimension=32, device=gpu_device,
                 base_config=_mpn_cfg(stack={"layer_norm": None, "num_steps": 1, "residual_connections": None,
