@@ -43,11 +43,33 @@ class AmberMpnDesc(C.Structure):
     ]
 
 
+TRANSFORM = {None: 0, False: 0, "none": 0, "null": 0, "softplus": 1, "exp": 2, "exponential": 2}
+
+
+class AmberGlueDesc(C.Structure):
+    _fields_ = [
+        ("normalize_inputs", C.c_int32),
+        ("denormalize_predictions", C.c_int32),
+        ("transform", C.c_int32),
+        ("predict_residual", C.c_int32),
+        ("apply_transform", C.c_int32),
+        ("clip", C.c_int32),
+        ("clip_min", C.c_float),
+        ("clip_max", C.c_float),
+        ("scale0", C.c_float),
+        ("scale1", C.c_float),
+        ("input_clip", C.c_double),
+        ("epsilon", C.c_double),
+    ]
+
+
 _P = C.c_void_p
 _I64 = C.c_int64
 _I32 = C.c_int32
 _SZ = C.c_size_t
 _DESC = C.POINTER(AmberMpnDesc)
+_GLUE = C.POINTER(AmberGlueDesc)
+_F64 = C.c_double
 
 # name -> (restype, argtypes): every symbol include/amber_mpn.h declares
 SIGNATURES = {
@@ -73,6 +95,13 @@ SIGNATURES = {
     "amber_mpn_backward_workspace_bytes": (_SZ, [_DESC, _I64, _I64]),
     "amber_mpn_backward": (C.c_int, [_DESC, _P, _P, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P, _P,
                                      _SZ, _P]),
+    "amber_mpn_normalize_rows": (C.c_int, [_P, _I64, _I32, _P, _P, _F64, _F64, _P, _P]),
+    "amber_mpn_postprocess": (C.c_int, [_GLUE, _P, _P, _P, _P, _I64, _P, _P]),
+    "amber_mpn_postprocess_backward": (C.c_int, [_GLUE, _P, _P, _P, _P, _P, _I64, _P, _P]),
+    "amber_mpn_inverse_transform": (C.c_int, [_I32, _P, _I64, _P, _P]),
+    "amber_mpn_predict_workspace_bytes": (_SZ, [_DESC, _I64, _I64]),
+    "amber_mpn_predict": (C.c_int, [_DESC, _GLUE, _P, _P, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                                    _P, _SZ, _P]),
 }
 
 _lib = None

@@ -1,9 +1,11 @@
 """The model AMBER calls (mirror of /root/reference/src/algorithm/architecture/supervised_mpn.py:10-56):
 MPN -> x[mask_output] -> decoder MLP -> readout Linear(L, 1), as one call into libamber_mpn.so."""
+import ctypes as C
+
 import torch
 import torch.nn as nn
 
-from amber_amd import engine
+from amber_amd import _lib, engine
 from amber_amd.architecture.mlp import MLP
 from amber_amd.mpn.get_message_passing_base import get_mpn_from_graph
 
@@ -48,4 +50,54 @@ class SupervisedMPN(nn.Module):
                                         + ([self.readout.bias] if n_out == 1 else []))
         _, _, out = engine.forward(desc, flat, packed, observations.x, observations.edge_attr, csr, want_node=False,
                                    want_edge=False, out_index=out_index, n_out=n_out)
+        return out
+
+    def fused_predict(self, observations, glue_desc, node_normalizer, edge_normalizer, prediction_normalizer, baseline) -> torch.Tensor:
+        """amber_mpn_predict: input normalisation + forward + post-processing of the readout in one C call (inference;
+        see amber_amd.predict.predict).  The *_normalizer arguments are TorchRunningMeanStd modules or None."""
+        observations, csr = self.mpn.prepare(observations)
+        n, e = csr.num_nodes, csr.num_edges
+        out_index, n_out = None, n
+        if hasattr(observations, "mask_output"):
+            out_index, n_out = engine.out_index_from_mask(observations.mask_output)
+        dec = self.decoder_mlp
+        desc = engine.make_desc(has_head=True, decoder_layers=dec.num_layers, decoder_activation=dec.activation_function,
+                                decoder_norm=dec.latent_normalization, **self.mpn.desc_kwargs())
+        dec_pieces, dec_sources = dec.param_list(single_row=(n_out == 1))
+        base = self.mpn.param_list()
+        tail = [self.readout.weight, self.readout.bias]
+        flat, packed = self._packed.get(desc, base + dec_pieces + tail, key_tensors=base + dec_sources + tail
+                                        + ([self.readout.bias] if n_out == 1 else []))
+        x, edge_attr = observations.x, observations.edge_attr
+        engine._require_cuda(x, "x")
+        engine._require_cuda(edge_attr, "edge_attr")
+        dev = x.device
+        x, edge_attr = engine._f32c(x), engine._f32c(edge_attr)
+        if x.shape[0] != n or edge_attr.shape[0] != e:
+            raise ValueError(f"Must provide one edge index per edge feature vector, given '{(2, e)}' and '{tuple(edge_attr.shape)}' instead.")
+
+        def stats(m, width, what):
+            if m is None or width == 0:
+                return None, None
+            if m.mean.numel() != width:
+                raise ValueError(f"amber_amd: {what} statistics of {m.mean.numel()} features, expected {width}")
+            return m.mean.to(dev).contiguous(), m.var.to(dev).contiguous()
+
+        nm, nv = stats(node_normalizer, desc.in_node_features, "node")
+        em, ev = stats(edge_normalizer, desc.in_edge_features, "edge")
+        pm, pv = stats(prediction_normalizer, 1, "prediction")
+        if baseline is not None:
+            baseline = baseline.to(device=dev, dtype=torch.float32).contiguous().view(-1)
+            if baseline.numel() != n_out:
+                raise ValueError(f"amber_amd: {n_out} predictions but a baseline (current_sizing_field) of {baseline.numel()}")
+        lib = _lib.load()
+        ws = torch.empty(lib.amber_mpn_predict_workspace_bytes(C.byref(desc), n, e), dtype=torch.uint8, device=dev)
+        out = torch.empty(n_out, 1, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.amber_mpn_predict(
+                C.byref(desc), C.byref(glue_desc), flat.data_ptr(), packed.data_ptr(), n, e, _lib.ptr(x), _lib.ptr(edge_attr),
+                csr.rowptr.data_ptr(), _lib.ptr(csr.src_sorted), _lib.ptr(csr.dst_sorted), _lib.ptr(csr.perm), _lib.ptr(out_index),
+                _lib.ptr(nm), _lib.ptr(nv), _lib.ptr(em), _lib.ptr(ev), _lib.ptr(pm), _lib.ptr(pv), _lib.ptr(baseline), out.data_ptr(),
+                ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev))
+        _lib.check(rc, "predict")
         return out

@@ -390,7 +390,8 @@ int run_embedding(const AmberMpnDesc& d, const MlpLayout& m, int F, const float*
 int forward_impl(const AmberMpnDesc* desc, const float* params, const float* packed, int64_t N, int64_t E, const float* x,
                  const float* edge_attr, const int32_t* rowptr, const int32_t* src_sorted, const int32_t* dst_sorted,
                  const int32_t* perm, const int32_t* out_index, float* out_node, float* out_edge, float* out_sizing,
-                 void* workspace, size_t workspace_bytes, hipStream_t s, Timer& tm, float* tape = nullptr) {
+                 void* workspace, size_t workspace_bytes, hipStream_t s, Timer& tm, float* tape = nullptr,
+                 const PostArgs* post = nullptr) {
   int rc = validate(desc);
   if (rc) return rc;
   const AmberMpnDesc& d = *desc;
@@ -430,7 +431,10 @@ int forward_impl(const AmberMpnDesc* desc, const float* params, const float* pac
     a.N = N;
     a.x_in = xbuf(0);
     a.x_out = out_node;
-    if (want_head) fill_node_head(a, d, lay, params, packed, out_index, out_sizing);
+    if (want_head) {
+      fill_node_head(a, d, lay, params, packed, out_index, out_sizing);
+      if (post) a.post = *post;
+    }
     if (out_node || want_head) {
       tm.begin(AMBER_KC_NODE);
       hipError_t e = launch_node(L, a, s);
@@ -502,6 +506,7 @@ int forward_impl(const AmberMpnDesc* desc, const float* params, const float* pac
       na.x_out = tape ? xbuf(it + 1) : out_node;
       if (want_head) {
         fill_node_head(na, d, lay, params, packed, out_index, out_sizing);
+        if (post) na.post = *post;
         if (na.fast && !na.x_out) na.x_out = w.x;  // the head runs as a launch of its own on the updated rows
       }
     }
@@ -1076,6 +1081,142 @@ int amber_mpn_backward(const AmberMpnDesc* desc, const float* params, const floa
   return backward_impl(desc, params, packed, N, E, x, edge_attr, rowptr, src_sorted, dst_sorted, perm, rowptr_src, perm_src, out_index,
                        grad_node, grad_edge, grad_sizing, static_cast<float*>(aligned_ws(tape)), grad_params, aligned_ws(workspace),
                        static_cast<hipStream_t>(stream));
+}
+
+// ---- pre / post glue of _predict ----
+static int make_post_args(const AmberGlueDesc* g, const float* baseline, const double* pred_mean, const double* pred_var,
+                          bool differentiable, PostArgs& p) {
+  if (!g) return fail(AMBER_ERR_INVALID_ARGUMENT, "glue is NULL");
+  if (g->transform < AMBER_TRANSFORM_NONE || g->transform > AMBER_TRANSFORM_EXP)
+    return fail(AMBER_ERR_UNSUPPORTED, "Unsupported transform type: id %d", g->transform);
+  if (g->denormalize_predictions && (!pred_mean || !pred_var))
+    return fail(AMBER_ERR_INVALID_ARGUMENT, "denormalize_predictions needs pred_mean / pred_var");
+  if (g->apply_transform && g->predict_residual && !baseline)
+    return fail(AMBER_ERR_INVALID_ARGUMENT, "Baseline must be provided for residual prediction.");
+  if (differentiable && (g->clip || g->scale0 != 1.f || g->scale1 != 1.f))
+    return fail(AMBER_ERR_INVALID_ARGUMENT, "clip / damping belong to the detached inference path and have no gradient");
+  p = PostArgs{};
+  p.on = 1;
+  p.denorm = g->denormalize_predictions ? 1 : 0;
+  p.transform = g->transform;
+  p.residual = g->predict_residual ? 1 : 0;
+  p.apply_transform = g->apply_transform ? 1 : 0;
+  p.clip = g->clip & 3;
+  p.mean = pred_mean;
+  p.var = pred_var;
+  p.eps = g->epsilon;
+  p.baseline = baseline;
+  p.clip_min = g->clip_min;
+  p.clip_max = g->clip_max;
+  p.scale0 = g->scale0;
+  p.scale1 = g->scale1;
+  return AMBER_OK;
+}
+
+int amber_mpn_normalize_rows(const float* in, int64_t rows, int32_t width, const double* mean, const double* var, double epsilon,
+                             double clip, float* out, void* stream) {
+  if (rows < 0 || width < 0) return fail(AMBER_ERR_INVALID_ARGUMENT, "negative size");
+  if (rows * width == 0) return AMBER_OK;
+  if (!in || !out || !mean || !var) return fail(AMBER_ERR_INVALID_ARGUMENT, "NULL pointer");
+  (void)hipGetLastError();
+  HIP_TRY(launch_normalize_rows(in, rows, width, mean, var, epsilon, clip, out, static_cast<hipStream_t>(stream)), "normalize_rows");
+  return AMBER_OK;
+}
+
+int amber_mpn_postprocess(const AmberGlueDesc* glue, const float* pred, const float* baseline, const double* pred_mean,
+                          const double* pred_var, int64_t n, float* out, void* stream) {
+  PostArgs p;
+  int rc = make_post_args(glue, baseline, pred_mean, pred_var, false, p);
+  if (rc) return rc;
+  if (n < 0) return fail(AMBER_ERR_INVALID_ARGUMENT, "negative size");
+  if (n == 0) return AMBER_OK;
+  if (!pred || !out) return fail(AMBER_ERR_INVALID_ARGUMENT, "pred / out is NULL");
+  (void)hipGetLastError();
+  HIP_TRY(launch_postprocess(p, pred, n, out, static_cast<hipStream_t>(stream)), "postprocess");
+  return AMBER_OK;
+}
+
+int amber_mpn_postprocess_backward(const AmberGlueDesc* glue, const float* pred, const float* baseline, const double* pred_mean,
+                                   const double* pred_var, const float* grad_out, int64_t n, float* grad_pred, void* stream) {
+  PostArgs p;
+  int rc = make_post_args(glue, baseline, pred_mean, pred_var, true, p);
+  if (rc) return rc;
+  if (n < 0) return fail(AMBER_ERR_INVALID_ARGUMENT, "negative size");
+  if (n == 0) return AMBER_OK;
+  if (!pred || !grad_out || !grad_pred) return fail(AMBER_ERR_INVALID_ARGUMENT, "pred / grad_out / grad_pred is NULL");
+  (void)hipGetLastError();
+  HIP_TRY(launch_postprocess_bwd(p, pred, grad_out, n, grad_pred, static_cast<hipStream_t>(stream)), "postprocess backward");
+  return AMBER_OK;
+}
+
+int amber_mpn_inverse_transform(int32_t transform, const float* in, int64_t n, float* out, void* stream) {
+  if (transform < AMBER_TRANSFORM_NONE || transform > AMBER_TRANSFORM_EXP)
+    return fail(AMBER_ERR_UNSUPPORTED, "Unsupported transform type: id %d", transform);
+  if (n < 0) return fail(AMBER_ERR_INVALID_ARGUMENT, "negative size");
+  if (n == 0) return AMBER_OK;
+  if (!in || !out) return fail(AMBER_ERR_INVALID_ARGUMENT, "in / out is NULL");
+  (void)hipGetLastError();
+  HIP_TRY(launch_inverse_transform(transform, in, n, out, static_cast<hipStream_t>(stream)), "inverse_transform");
+  return AMBER_OK;
+}
+
+// workspace of amber_mpn_predict: [forward workspace | normalised x | normalised edge_attr]
+static size_t predict_norm_bytes(const AmberMpnDesc* d, int64_t N, int64_t E, size_t* xb_out) {
+  const size_t xb = align256(sizeof(float) * static_cast<size_t>(N) * d->in_node_features);
+  const size_t eb = align256(sizeof(float) * static_cast<size_t>(E) * d->in_edge_features);
+  if (xb_out) *xb_out = xb;
+  return xb + eb;
+}
+size_t amber_mpn_predict_workspace_bytes(const AmberMpnDesc* desc, int64_t num_nodes, int64_t num_edges) {
+  const size_t fw = amber_mpn_workspace_bytes(desc, num_nodes, num_edges);
+  if (fw == 0) return 0;
+  return fw + predict_norm_bytes(desc, num_nodes, num_edges, nullptr);
+}
+
+int amber_mpn_predict(const AmberMpnDesc* desc, const AmberGlueDesc* glue, const float* params, const float* packed,
+                      int64_t num_nodes, int64_t num_edges, const float* x, const float* edge_attr, const int32_t* rowptr,
+                      const int32_t* src_sorted, const int32_t* dst_sorted, const int32_t* perm, const int32_t* out_index,
+                      const double* node_mean, const double* node_var, const double* edge_mean, const double* edge_var,
+                      const double* pred_mean, const double* pred_var, const float* baseline, float* out_sizing, void* workspace,
+                      size_t workspace_bytes, void* stream) {
+  int rc = validate(desc);
+  if (rc) return rc;
+  if (!desc->has_head) return fail(AMBER_ERR_INVALID_ARGUMENT, "amber_mpn_predict needs desc->has_head == 1");
+  if (!out_sizing) return fail(AMBER_ERR_INVALID_ARGUMENT, "out_sizing is NULL");
+  PostArgs p;
+  rc = make_post_args(glue, baseline, pred_mean, pred_var, false, p);
+  if (rc) return rc;
+  if (num_nodes < 0 || num_edges < 0) return fail(AMBER_ERR_INVALID_ARGUMENT, "negative size");
+  if (!workspace) return fail(AMBER_ERR_INVALID_ARGUMENT, "workspace is NULL");
+  const size_t need = amber_mpn_predict_workspace_bytes(desc, num_nodes, num_edges);
+  if (workspace_bytes < need) return fail(AMBER_ERR_WORKSPACE_TOO_SMALL, "workspace %zu < %zu bytes", workspace_bytes, need);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  char* base = static_cast<char*>(aligned_ws(workspace));
+  const size_t fw = amber_mpn_workspace_bytes(desc, num_nodes, num_edges) - 256;  // carved size, without the alignment slack
+  const float* xin = x;
+  const float* ein = edge_attr;
+  if (glue->normalize_inputs) {
+    size_t xb = 0;
+    predict_norm_bytes(desc, num_nodes, num_edges, &xb);
+    float* xn = reinterpret_cast<float*>(base + align256(fw));
+    float* en = reinterpret_cast<float*>(base + align256(fw) + xb);
+    if (num_nodes > 0 && desc->in_node_features > 0) {
+      if (!x || !node_mean || !node_var) return fail(AMBER_ERR_INVALID_ARGUMENT, "x / node statistics are NULL");
+      HIP_TRY(launch_normalize_rows(x, num_nodes, desc->in_node_features, node_mean, node_var, glue->epsilon, glue->input_clip, xn, s),
+              "normalize x");
+      xin = xn;
+    }
+    if (num_edges > 0 && desc->in_edge_features > 0) {
+      if (!edge_attr || !edge_mean || !edge_var) return fail(AMBER_ERR_INVALID_ARGUMENT, "edge_attr / edge statistics are NULL");
+      HIP_TRY(launch_normalize_rows(edge_attr, num_edges, desc->in_edge_features, edge_mean, edge_var, glue->epsilon,
+                                    glue->input_clip, en, s),
+              "normalize edge_attr");
+      ein = en;
+    }
+  }
+  Timer tm;
+  return forward_impl(desc, params, packed, num_nodes, num_edges, xin, ein, rowptr, src_sorted, dst_sorted, perm, out_index, nullptr,
+                      nullptr, out_sizing, base, workspace_bytes, s, tm, nullptr, &p);
 }
 
 }  // extern "C"

@@ -58,6 +58,22 @@ struct EdgeArgs {
 };
 constexpr int kMaxFusedEmbed = 4;
 
+// Post-processing of the head's output inside the readout epilogue (or stand-alone): RunningNormalizer
+// ._denormalize, PredictionTransform.forward, _clip_detach, damping (see mpn_post.h).  on == 0: the raw network output.
+struct PostArgs {
+  int32_t on;
+  int32_t denorm;           // prediction normaliser present
+  int32_t transform;        // AMBER_TRANSFORM_*
+  int32_t residual;         // predict_residual: add transform^-1(baseline) before the transform
+  int32_t apply_transform;  // 0: training with inverse_transform_in_loss (the loss sees the denormalised raw output)
+  int32_t clip;             // bit 0: lower bound, bit 1: upper bound
+  const double* mean;       // [1] device
+  const double* var;        // [1] device
+  double eps;
+  const float* baseline;    // [N_m] current sizing field, indexed like the output
+  float clip_min, clip_max, scale0, scale1;
+};
+
 // Arguments of the fused node kernel (K6 finish, K7, K8, next step's first-layer projections, K9, K10).
 struct NodeArgs {
   int64_t N;
@@ -101,6 +117,7 @@ struct NodeArgs {
   const float* br;        // [1]
   const int32_t* out_index;  // [N] or nullptr
   float* out;
+  PostArgs post;          // applied to the readout value before it is stored
   int32_t dbg;            // experiment switches (AMBER_MPN_DBG), 0 in production
   int32_t single;         // AMBER_PREC_F16, as in EdgeArgs
 };
@@ -179,6 +196,14 @@ hipError_t launch_segment_reduce(const float* vals, const int32_t* rowptr, const
 hipError_t launch_rows_gemm_add(int L, float* io, const float* in0, const float* w0, const float* in1, const float* w1, int64_t rows,
                                 hipStream_t s);
 hipError_t launch_pack_t(int L, const float* W, int ld, int col0, float* out, hipStream_t s);
+
+// ---- pre / post glue of _predict, glue.hip ----
+hipError_t launch_normalize_rows(const float* in, int64_t rows, int width, const double* mean, const double* var, double eps,
+                                 double clip, float* out, hipStream_t s);
+hipError_t launch_inverse_transform(int transform, const float* in, int64_t n, float* out, hipStream_t s);
+hipError_t launch_postprocess(const PostArgs& p, const float* pred, int64_t n, float* out, hipStream_t s);
+hipError_t launch_postprocess_bwd(const PostArgs& p, const float* pred, const float* grad_out, int64_t n, float* grad_pred,
+                                  hipStream_t s);
 
 size_t csr_workspace_bytes(int64_t N, int64_t E);
 hipError_t csr_build(const int64_t* edge_index, int64_t E, int64_t N, int32_t* rowptr, int32_t* src_sorted,

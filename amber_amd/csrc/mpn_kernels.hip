@@ -21,6 +21,7 @@
 // Aggregation (scatter_mean) is fused into the edge kernel: the tile is staged in LDS and summed
 // sequentially per destination row in CSR order (deterministic, no atomics).  Rows cut by a tile
 // boundary leave partial sums in head/tail buffers that the node kernel adds in tile order.
+#include "mpn_post.h"
 #include "mpn_tile.h"
 
 namespace amber {
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(kBlock) void node_kernel(const NodeArgs a, const in
     s += a.br[0];
     if (h == 0 && c < nvalid) {
       const int64_t oi = a.out_index ? static_cast<int64_t>(a.out_index[n]) : n;
-      if (oi >= 0) a.out[oi] = s;
+      if (oi >= 0) a.out[oi] = a.post.on ? post_one(a.post, s, oi) : s;
     }
   }
 }

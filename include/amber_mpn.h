@@ -229,6 +229,67 @@ int amber_mpn_backward(const AmberMpnDesc* desc, const float* params, const floa
                        const float* grad_node, const float* grad_edge, const float* grad_sizing, void* tape,
                        size_t tape_bytes, float* grad_params, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------
+ * Pre / post numeric glue of the model call: what MeshGenerationAlgorithm._predict
+ * (src/algorithm/core/mesh_generation_algorithm.py:343-367) does either side of self.model(batch), and the clip + damping
+ * of the predicted sizing field that follows it in the inference step (_clip_detach :369-371, Amber._clip_detach_dampen
+ * src/algorithm/core/amber.py:213-246).
+ *
+ * Running statistics are the float64 buffers of TorchRunningMeanStd (src/algorithm/normalizer/torch_running_mean_std.py:
+ * 23-25), passed as DEVICE pointers (no host read of them is needed).  Integer/bit behaviour: the normalised inputs are
+ * bit-identical to the reference's (same IEEE float64 operations, one rounding to float32); the post-processing uses
+ * float32 exp / log / expm1 / log1p, equal to the reference's within 1e-6 relative.
+ * ------------------------------------------------------------------------------------------------- */
+enum { AMBER_TRANSFORM_NONE = 0, AMBER_TRANSFORM_SOFTPLUS = 1, AMBER_TRANSFORM_EXP = 2 };
+
+typedef struct AmberGlueDesc {
+  int32_t normalize_inputs;        /* node / edge normalisers present (graph_running_normalizer.py:60-67) */
+  int32_t denormalize_predictions; /* prediction normaliser present (running_normalizer.py:35-38, :82-85) */
+  int32_t transform;               /* AMBER_TRANSFORM_* (src/algorithm/prediction_transform/__init__.py:6-27) */
+  int32_t predict_residual;        /* prediction + transform^-1(baseline) before the transform (prediction_transform.py:78-86) */
+  int32_t apply_transform;         /* 0 = is_train with inverse_transform_in_loss: raw output (prediction_transform.py:75-76) */
+  int32_t clip;                    /* bit 0: clip_min set, bit 1: clip_max set (np.clip with None bounds) */
+  float clip_min, clip_max;        /* gmsh_kwargs min_sizing_field / max_sizing_field */
+  float scale0;                    /* damping: 1 / damping_factor ** (inference_steps - depth - 1), or 1 */
+  float scale1;                    /* last_step_damping, or 1 */
+  double input_clip;               /* maximum |normalised input| (normalizer yaml: 20) */
+  double epsilon;                  /* added to the variances (running_normalizer.py:18: 1e-6) */
+} AmberGlueDesc;
+
+/* RunningNormalizer._normalize (running_normalizer.py:87-106): out = float32(clip((in - mean) / sqrt(var + epsilon), +-clip)),
+ * rows x width values, mean / var float64 [width] on the device.  Bit-identical to the reference. */
+int amber_mpn_normalize_rows(const float* in, int64_t rows, int32_t width, const double* mean, const double* var,
+                             double epsilon, double clip, float* out, void* stream);
+
+/* RunningNormalizer.denormalize_predictions (running_normalizer.py:82-85,108-119) + PredictionTransform.forward
+ * (prediction_transform.py:58-88) + clip + damping on n network outputs.  pred_mean / pred_var: float64 [1] (ignored
+ * unless glue->denormalize_predictions); baseline: current sizing field [n] (needed iff predict_residual and the
+ * transform is applied). */
+int amber_mpn_postprocess(const AmberGlueDesc* glue, const float* pred, const float* baseline, const double* pred_mean,
+                          const double* pred_var, int64_t n, float* out, void* stream);
+/* Gradient of amber_mpn_postprocess with respect to pred (training: the loss sees the post-processed value).  Clip and
+ * damping are part of the detached inference path and must be off. */
+int amber_mpn_postprocess_backward(const AmberGlueDesc* glue, const float* pred, const float* baseline,
+                                   const double* pred_mean, const double* pred_var, const float* grad_out, int64_t n,
+                                   float* grad_pred, void* stream);
+
+/* transform^-1 on n values (labels into network space for the loss and the label statistics:
+ * PredictionTransform.inverse, prediction_transform.py:90-128): softplus: v + log(-expm1(-v)); exp: log(v); none: v. */
+int amber_mpn_inverse_transform(int32_t transform, const float* in, int64_t n, float* out, void* stream);
+
+/* _predict in one call (inference): normalise x and edge_attr into the workspace, run amber_mpn_forward with the
+ * SupervisedMPN head, and apply the post-processing inside the head kernel's readout epilogue (no pass of its own).
+ * Replaces mesh_generation_algorithm.py:353-366 (+ the clip / damping of amber.py:213-246 when the glue asks for them).
+ * desc->has_head must be 1.  workspace: amber_mpn_predict_workspace_bytes.  node_* / edge_* statistics: float64
+ * [F_n] / [F_e] (ignored unless glue->normalize_inputs; a width of 0 needs none). */
+size_t amber_mpn_predict_workspace_bytes(const AmberMpnDesc* desc, int64_t num_nodes, int64_t num_edges);
+int amber_mpn_predict(const AmberMpnDesc* desc, const AmberGlueDesc* glue, const float* params, const float* packed,
+                      int64_t num_nodes, int64_t num_edges, const float* x, const float* edge_attr, const int32_t* rowptr,
+                      const int32_t* src_sorted, const int32_t* dst_sorted, const int32_t* perm, const int32_t* out_index,
+                      const double* node_mean, const double* node_var, const double* edge_mean, const double* edge_var,
+                      const double* pred_mean, const double* pred_var, const float* baseline, float* out_sizing,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
 int amber_mpn_abi_version(void);
 const char* amber_mpn_last_error(void);
 

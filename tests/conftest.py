@@ -18,7 +18,18 @@ def pytest_configure(config):
 
 
 def golden_cases():
-    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz"))
+    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and not f.startswith("glue_"))
+
+
+def glue_cases():
+    return sorted(f[5:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and f.startswith("glue_"))
+
+
+def load_glue(name):
+    """One pre / post glue fixture written by tests/golden/make_golden_glue.py: (meta dict, {name: tensor})."""
+    z = np.load(os.path.join(GOLDEN_DIR, f"glue_{name}.npz"), allow_pickle=False)
+    meta = json.loads(str(z["meta"]))
+    return meta, {k: torch.from_numpy(z[k]) for k in z.files if k != "meta"}
 
 
 def load_golden(name):
