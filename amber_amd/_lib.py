@@ -63,6 +63,10 @@ class AmberGlueDesc(C.Structure):
     ]
 
 
+class AmberGraphDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("dim", "add_self_edges", "distance_vector", "euclidean_distance", "edge_curvature")]
+
+
 _P = C.c_void_p
 _I64 = C.c_int64
 _I32 = C.c_int32
@@ -99,6 +103,8 @@ SIGNATURES = {
     "amber_mpn_postprocess": (C.c_int, [_GLUE, _P, _P, _P, _P, _I64, _P, _P]),
     "amber_mpn_postprocess_backward": (C.c_int, [_GLUE, _P, _P, _P, _P, _P, _I64, _P, _P]),
     "amber_mpn_inverse_transform": (C.c_int, [_I32, _P, _I64, _P, _P]),
+    "amber_mpn_graph_edge_features": (_I32, [C.POINTER(AmberGraphDesc)]),
+    "amber_mpn_build_graph": (C.c_int, [C.POINTER(AmberGraphDesc), _I32, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P, _P, _P, _P, _P]),
     "amber_mpn_predict_workspace_bytes": (_SZ, [_DESC, _I64, _I64]),
     "amber_mpn_predict": (C.c_int, [_DESC, _GLUE, _P, _P, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                     _P, _SZ, _P]),

@@ -1219,4 +1219,55 @@ int amber_mpn_predict(const AmberMpnDesc* desc, const AmberGlueDesc* glue, const
                       nullptr, out_sizing, base, workspace_bytes, s, tm, nullptr, &p);
 }
 
+// ---- graph construction ----
+int32_t amber_mpn_graph_edge_features(const AmberGraphDesc* g) {
+  if (!g || (g->dim != 2 && g->dim != 3)) return -1;
+  return (g->distance_vector ? g->dim : 0) + (g->euclidean_distance ? 1 : 0) + (g->edge_curvature ? 1 : 0);
+}
+
+int amber_mpn_build_graph(const AmberGraphDesc* gdesc, int32_t num_graphs, const int64_t* node_ptr, const int64_t* edge_ptr,
+                          const int64_t* nbr_a, const int64_t* nbr_b, const float* positions, const float* curvature,
+                          int64_t num_nodes, int64_t num_pairs, int64_t* edge_index, float* edge_attr, int64_t* batch,
+                          float* degree, int32_t* status, void* stream) {
+  if (!gdesc) return fail(AMBER_ERR_INVALID_ARGUMENT, "gdesc is NULL");
+  if (gdesc->dim != 2 && gdesc->dim != 3) return fail(AMBER_ERR_UNSUPPORTED, "positions must have 2 or 3 columns, given %d", gdesc->dim);
+  if (num_graphs < 0 || num_nodes < 0 || num_pairs < 0) return fail(AMBER_ERR_INVALID_ARGUMENT, "negative size");
+  if (!status) return fail(AMBER_ERR_INVALID_ARGUMENT, "status is NULL");
+  if ((num_nodes > 0 || num_pairs > 0) && (num_graphs == 0 || !node_ptr || !edge_ptr))
+    return fail(AMBER_ERR_INVALID_ARGUMENT, "node_ptr / edge_ptr missing");
+  if (num_pairs > 0 && num_nodes == 0) return fail(AMBER_ERR_INVALID_ARGUMENT, "pairs without nodes");
+  const int F = amber_mpn_graph_edge_features(gdesc);
+  const int64_t E = 2 * num_pairs + (gdesc->add_self_edges ? num_nodes : 0);
+  if (num_pairs > 0 && (!nbr_a || !nbr_b)) return fail(AMBER_ERR_INVALID_ARGUMENT, "nbr_a / nbr_b is NULL");
+  if (E > 0 && !edge_index) return fail(AMBER_ERR_INVALID_ARGUMENT, "edge_index is NULL");
+  if (E > 0 && F > 0 && !edge_attr) return fail(AMBER_ERR_INVALID_ARGUMENT, "edge_attr is NULL");
+  if (num_pairs > 0 && (gdesc->distance_vector || gdesc->euclidean_distance) && !positions)
+    return fail(AMBER_ERR_INVALID_ARGUMENT, "positions is NULL");
+  (void)hipGetLastError();
+  GraphArgs a{};
+  a.G = num_graphs;
+  a.dim = gdesc->dim;
+  a.add_self_edges = gdesc->add_self_edges ? 1 : 0;
+  a.distance_vector = gdesc->distance_vector ? 1 : 0;
+  a.euclidean_distance = gdesc->euclidean_distance ? 1 : 0;
+  a.edge_curvature = gdesc->edge_curvature ? 1 : 0;
+  a.F = F;
+  a.N = num_nodes;
+  a.M = num_pairs;
+  a.E = E;
+  a.node_ptr = node_ptr;
+  a.edge_ptr = edge_ptr;
+  a.nbr_a = nbr_a;
+  a.nbr_b = nbr_b;
+  a.positions = positions;
+  a.curvature = gdesc->edge_curvature ? curvature : nullptr;
+  a.edge_index = edge_index;
+  a.edge_attr = edge_attr;
+  a.batch = batch;
+  a.degree_i = reinterpret_cast<int32_t*>(degree);
+  a.status = status;
+  HIP_TRY(launch_build_graph(a, static_cast<hipStream_t>(stream)), "build_graph");
+  return AMBER_OK;
+}
+
 }  // extern "C"

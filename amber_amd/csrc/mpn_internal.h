@@ -205,6 +205,24 @@ hipError_t launch_postprocess(const PostArgs& p, const float* pred, int64_t n, f
 hipError_t launch_postprocess_bwd(const PostArgs& p, const float* pred, const float* grad_out, int64_t n, float* grad_pred,
                                   hipStream_t s);
 
+// ---- graph construction, graph.hip ----
+struct GraphArgs {
+  int32_t G, dim, add_self_edges, distance_vector, euclidean_distance, edge_curvature, F;
+  int64_t N, M, E;             // nodes, undirected pairs, directed edges written (2 M + N with self edges)
+  const int64_t* node_ptr;     // [G+1]
+  const int64_t* edge_ptr;     // [G+1]
+  const int64_t* nbr_a;        // [M] local ids
+  const int64_t* nbr_b;        // [M]
+  const float* positions;      // [N, dim] or nullptr
+  const float* curvature;      // [M] or nullptr
+  int64_t* edge_index;         // [2, E]
+  float* edge_attr;            // [E, F]
+  int64_t* batch;              // [N] or nullptr
+  int32_t* degree_i;           // [N] or nullptr: int32 counts, converted to float32 in place
+  int32_t* status;
+};
+hipError_t launch_build_graph(const GraphArgs& a, hipStream_t s);
+
 size_t csr_workspace_bytes(int64_t N, int64_t E);
 hipError_t csr_build(const int64_t* edge_index, int64_t E, int64_t N, int32_t* rowptr, int32_t* src_sorted,
                      int32_t* dst_sorted, int32_t* perm, int32_t* status, void* ws, hipStream_t s);

@@ -290,6 +290,34 @@ int amber_mpn_predict(const AmberMpnDesc* desc, const AmberGlueDesc* glue, const
                       const double* pred_mean, const double* pred_var, const float* baseline, float* out_sizing,
                       void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------
+ * Graph construction on the device: the step before the path.  For a batch of G meshes,
+ * each given by its undirected neighbour pairs (local ids; MeshWrapper.mesh_edges for vertex graphs,
+ * .element_neighbors for element graphs) and node positions (.vertex_positions / .element_midpoints), writes
+ *   edge_index [2, E] int64 : per graph [a -> b | b -> a | v -> v], ids offset by the nodes of the graphs before it
+ *   edge_attr  [E, F] fp32  : columns in the reference's order: distance_vector (dim), euclidean_distance, edge_curvature
+ *   batch [N] int64 (graph id of every node), degree [N] fp32 (occurrences of the node among the pairs)
+ * E = 2 M + (add_self_edges ? N : 0), F = amber_mpn_graph_edge_features(gdesc).
+ * Replaces get_mesh_vertex_edges / get_mesh_element_edges (src/mesh_util/transforms/mesh_to_graph.py:58-145), the
+ * "degree" feature (:224-225) and the collation of Batch.from_data_list reached through make_batch
+ * (src/helpers/torch_util.py:34-55).  edge_index / batch / degree are bit-exact; so are the float features (IEEE
+ * subtract, multiply, add, sqrt in the reference's order).  node_ptr / edge_ptr: int64 [G+1] DEVICE arrays (prefix sums
+ * of the per-graph node and pair counts).  curvature: one value per undirected pair (0 off the boundary) or NULL = 0.
+ * status: int32[1], 0, or 1 if a local id is outside its graph (clamped).  batch / degree may be NULL.
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct AmberGraphDesc {
+  int32_t dim;                /* columns of positions: 2 or 3 */
+  int32_t add_self_edges;
+  int32_t distance_vector;    /* edge feature flags ("distance_vector", "euclidean_distance", "edge_curvature") */
+  int32_t euclidean_distance;
+  int32_t edge_curvature;
+} AmberGraphDesc;
+int32_t amber_mpn_graph_edge_features(const AmberGraphDesc* gdesc);
+int amber_mpn_build_graph(const AmberGraphDesc* gdesc, int32_t num_graphs, const int64_t* node_ptr, const int64_t* edge_ptr,
+                          const int64_t* nbr_a, const int64_t* nbr_b, const float* positions, const float* curvature,
+                          int64_t num_nodes, int64_t num_pairs, int64_t* edge_index, float* edge_attr, int64_t* batch,
+                          float* degree, int32_t* status, void* stream);
+
 int amber_mpn_abi_version(void);
 const char* amber_mpn_last_error(void);
 

@@ -18,11 +18,21 @@ def pytest_configure(config):
 
 
 def golden_cases():
-    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and not f.startswith("glue_"))
+    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and not f.startswith(("glue_", "graph_")))
 
 
 def glue_cases():
     return sorted(f[5:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and f.startswith("glue_"))
+
+
+def graph_cases():
+    return sorted(f[6:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and f.startswith("graph_"))
+
+
+def load_graph(name):
+    """One graph-construction fixture written by tests/golden/make_golden_graph.py: (meta dict, {name: ndarray})."""
+    z = np.load(os.path.join(GOLDEN_DIR, f"graph_{name}.npz"), allow_pickle=False)
+    return json.loads(str(z["meta"])), {k: z[k] for k in z.files if k != "meta"}
 
 
 def load_glue(name):
