@@ -50,6 +50,7 @@ struct Layout {
   std::vector<MlpLayout> edge, node;
   std::vector<int64_t> eg, eb, ng, nb;  // LayerNorm params per step (or -1)
   MlpLayout dec;
+  int64_t dec_f2[kMaxLayers];  // packed offsets of the decoder matrices in the split-precision format, or -1
   int64_t readout_w, readout_b;
   int64_t n_params, n_packed;
 };
@@ -82,6 +83,8 @@ int validate(const AmberMpnDesc* d) {
   if (!(d->ln_eps > 0.f)) return fail(AMBER_ERR_INVALID_ARGUMENT, "ln_eps must be > 0");
   return AMBER_OK;
 }
+
+bool use_fast_head(const AmberMpnDesc& d);
 
 Layout build_layout(const AmberMpnDesc& d) {
   Layout lay;
@@ -152,9 +155,15 @@ Layout build_layout(const AmberMpnDesc& d) {
     }
   }
   lay.dec.layers = 0;
+  for (int l = 0; l < kMaxLayers; ++l) lay.dec_f2[l] = -1;
   lay.readout_w = lay.readout_b = -1;
   if (d.has_head) {
     mlp(lay.dec, d.decoder_layers, d.latent, 1, d.decoder_norm != AMBER_NORM_NONE, true);
+    if (use_fast_head(d))
+      for (int l = 0; l < d.decoder_layers; ++l) {
+        lay.dec_f2[l] = pk;
+        pk += L * L + kPackedHeader;
+      }
     lay.readout_w = po;
     po += L;
     lay.readout_b = po;
@@ -260,6 +269,11 @@ bool use_fast_edge(const AmberMpnDesc& d) {
 bool use_fast_node(const AmberMpnDesc& d) {
   return d.precision != AMBER_PREC_FP32 && node_f2_supported(d.latent, d.activation, d.residual, d.layer_norm);
 }
+// the head rides on the last split-precision node launch (decoder layers as further phases, readout in the epilogue)
+bool use_fast_head(const AmberMpnDesc& d) {
+  return d.has_head && use_fast_node(d) && d.num_steps * d.num_step_repeats > 0 &&
+         head_f2_supported(d.decoder_layers, d.decoder_activation, d.decoder_norm) && !getenv("AMBER_MPN_NO_FUSED_HEAD");
+}
 int device_cus() {
   int dev = 0, cus = 0;
   if (hipGetDevice(&dev) != hipSuccess) return 256;
@@ -284,11 +298,15 @@ hipError_t run_node(const AmberMpnDesc& d, const NodeArgs& na, hipStream_t s) {
   const char* dbg = getenv("AMBER_MPN_DBG");
   u.dbg = dbg ? atoi(dbg) : 0;
   u.single = d.precision == AMBER_PREC_F16 ? 1 : 0;
-  u.n_dense = 0;
-  u.do_readout = 0;
-  u.dense_out = nullptr;
+  // the head joins this launch when its matrices exist in the split-precision format and the update runs here too
+  const bool head_here = na.do_readout && na.do_update && !na.dense_out && na.n_dense > 0 && na.dense_f2[0] != nullptr;
+  if (!head_here) {
+    u.n_dense = 0;
+    u.do_readout = 0;
+    u.dense_out = nullptr;
+  }
   hipError_t e = launch_node_f2(d.latent, u, device_cus(), s);
-  if (e != hipSuccess || (na.n_dense == 0 && !na.do_readout)) return e;
+  if (e != hipSuccess || head_here || (na.n_dense == 0 && !na.do_readout)) return e;
   NodeArgs hd = na;
   hd.fast = 0;
   hd.do_update = 0;
@@ -349,8 +367,11 @@ void fill_node_head(NodeArgs& a, const AmberMpnDesc& d, const Layout& lay, const
   a.dense_act = d.decoder_activation;
   a.dense_norm = d.decoder_norm;
   for (int l = 0; l < d.decoder_layers; ++l)
+  {
     a.dense[l] = DenseLayer{packed + lay.dec.PW[l][0], params + lay.dec.B[l], lay.dec.P[l] >= 0 ? params + lay.dec.P[l] : nullptr,
                             lay.dec.Q[l] >= 0 ? params + lay.dec.Q[l] : nullptr};
+    a.dense_f2[l] = lay.dec_f2[l] >= 0 ? packed + lay.dec_f2[l] : nullptr;
+  }
   a.do_readout = 1;
   a.wr = params + lay.readout_w;
   a.br = params + lay.readout_b;
@@ -507,7 +528,7 @@ int forward_impl(const AmberMpnDesc* desc, const float* params, const float* pac
       if (want_head) {
         fill_node_head(na, d, lay, params, packed, out_index, out_sizing);
         if (post) na.post = *post;
-        if (na.fast && !na.x_out) na.x_out = w.x;  // the head runs as a launch of its own on the updated rows
+        if (na.fast && !na.x_out && !na.dense_f2[0]) na.x_out = w.x;  // the head runs as a launch of its own on the updated rows
       }
     }
     tm.begin(AMBER_KC_NODE);
@@ -840,7 +861,12 @@ int amber_mpn_pack_weights(const AmberMpnDesc* desc, const float* params, float*
     HIP_TRY(pack_mlp(lay.edge[st], 3, fn, fn, fe, false, fe), "pack edge MLP");
     HIP_TRY(pack_mlp(lay.node[st], 2, fn, fn, FMT_F32, true, fn), "pack node MLP");
   }
-  if (desc->has_head) HIP_TRY(pack_mlp(lay.dec, 1), "pack decoder");
+  if (desc->has_head) {
+    HIP_TRY(pack_mlp(lay.dec, 1), "pack decoder");
+    for (int l = 0; l < desc->decoder_layers; ++l)
+      if (lay.dec_f2[l] >= 0)
+        HIP_TRY(launch_pack_f2(L, params + lay.dec.W[l], L, 0, 0, L, packed + lay.dec_f2[l], s), "pack decoder (split precision)");
+  }
   return AMBER_OK;
 }
 

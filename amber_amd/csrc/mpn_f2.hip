@@ -26,6 +26,7 @@
 // 2 x 64 KB) and walk the CSR-ordered edge tiles; each wave owns a tile end to end (no workgroup barrier in the
 // loop).  reference: MessagePassingEdgeModule.forward (src/mpn/message_passing_modules.py:38-52),
 // MessagePassingBlock.forward (src/mpn/message_passing_block.py:117-121), scatter_mean (message_passing_modules.py:68).
+#include "mpn_post.h"
 #include "mpn_tile.h"
 
 // experiment switches for tools/exp_dbg.py (timing only, results are wrong with a switch on): build with
@@ -579,7 +580,9 @@ __global__ __launch_bounds__(kF2Block) void edge_kernel_f2(const EdgeArgs a, con
 // matrix streams into the other slot by LDS-DMA (global_load_lds), and one workgroup barrier separates the phases.
 // When all matrices fit (L <= 64) they are loaded once and the phases run without barriers.
 // ---------------------------------------------------------------------------------------------------
-template <int L, bool SPLIT>
+// HEAD: the instantiation of the LAST node launch of a SupervisedMPN forward - no projections follow, the decoder's
+// layers and the readout do (kept apart so that neither variant pays the other's registers).
+template <int L, bool SPLIT, bool HEAD>
 __global__ __launch_bounds__(kF2Block) void node_kernel_f2(const NodeArgs a, const int64_t ntiles, const int resident) {
   constexpr int NFB = L / 32;
   constexpr int MAT_BYTES = L * L * 4;
@@ -587,11 +590,14 @@ __global__ __launch_bounds__(kF2Block) void node_kernel_f2(const NodeArgs a, con
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave id as a scalar
   const int n = lane & 31, h = lane >> 5;
   const int nu = a.do_update ? a.nl + 1 : 0;   // phases of the update: W0x, W0a, hidden layers
-  const int P = nu + (a.do_proj ? 2 : 0);      // phases per batch of tiles
+  const int np = (!HEAD && a.do_proj) ? 2 : 0;  // phases of the projections: W0s, W0d
+  const int nd = HEAD ? a.n_dense : 0;          // phases of the decoder
+  const int P = nu + np + nd;                   // phases per batch of tiles
   // matrix of phase k (wave-uniform)
   auto mat = [&](int k) -> const float* {
     if (k < nu) return k == 0 ? a.w0x : (k == 1 ? a.w0a : a.layers[k - 1].w);
-    return k == nu ? a.w0s : a.w0d;
+    if (k < nu + np) return k == nu ? a.w0s : a.w0d;
+    return a.dense_f2[k - nu - np];
   };
   // this wave's share of one matrix, global -> LDS slot, no registers (1 KB per instruction)
   auto stream_in = [&](const float* src, int slot) {
@@ -813,7 +819,7 @@ __global__ __launch_bounds__(kF2Block) void node_kernel_f2(const NodeArgs a, con
       }
     };
     if (a.x_out && a.do_update) store_tile(a.x_out, v);
-    if (a.do_proj) {
+    if (!HEAD && a.do_proj) {
       float scale, inv;
       pow2_scale(wave_max(tile_absmax<L>(v)), scale, inv);
       {
@@ -849,6 +855,49 @@ __global__ __launch_bounds__(kF2Block) void node_kernel_f2(const NodeArgs a, con
         tile_scale<L>(acc, inv * a.w0d[L * L]);
         store_tile(a.Pd, acc);
       }
+    }
+    // ---- SupervisedMPN head on the updated rows (K9, K10: src/algorithm/architecture/supervised_mpn.py:51-54, MLP
+    // mlp.py:60-95 with relu / leakyrelu and no latent normalisation): the decoder's layers as further phases ----
+    if constexpr (HEAD) {
+#pragma unroll 1
+    for (int l = 0; l < a.n_dense; ++l) {
+      const unsigned char* wl = begin_phase(k++);
+      const float* wg = a.dense_f2[l];
+      float scale, inv;
+      pow2_scale(wave_max(tile_absmax<L>(v)), scale, inv);
+      Tile<L> nxt;
+      const float bs = scale * wg[L * L + 1];
+#pragma unroll
+      for (int fb = 0; fb < NFB; ++fb) {
+        const float bv = a.dense[l].b[32 * fb + nq] * bs;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) nxt.a[fb][i] = bv;
+      }
+      gemm_acc<L, SPLIT>(nxt, v, scale, win, wo, wl, lane);
+      tile_scale<L>(nxt, inv * wg[L * L]);
+      tile_act_fast<L>(nxt, a.dense_act);
+      v = nxt;
+    }
+    if (a.do_readout) {
+      // readout Linear(L, 1): a dot product over the features = over the lanes of a half, one register per row
+      float wq[NFB];
+#pragma unroll
+      for (int fb = 0; fb < NFB; ++fb) wq[fb] = a.wr[32 * fb + nq];
+      const float br = a.br[0];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        float sacc = v.a[0][i] * wq[0];
+#pragma unroll
+        for (int fb = 1; fb < NFB; ++fb) sacc = fmaf(v.a[fb][i], wq[fb], sacc);
+        const float tot = half_sum(sacc) + br;
+        const int r = 8 * (i >> 2) + (i & 3) + 4 * h;
+        if (n == 0 && r < nstore) {
+          const int64_t row = n0 + r;
+          const int64_t oi = a.out_index ? static_cast<int64_t>(a.out_index[row]) : row;
+          if (oi >= 0) a.out[oi] = a.post.on ? post_one(a.post, tot, oi) : tot;
+        }
+      }
+    }
     }
   }
 }
@@ -955,28 +1004,39 @@ bool node_f2_supported(int L, int act, int residual, int layer_norm) {
   return (act == AMBER_ACT_RELU || act == AMBER_ACT_LEAKYRELU) && residual != AMBER_MODE_OUTER && layer_norm != AMBER_MODE_OUTER;
 }
 
-template <int L, bool SPLIT>
+bool head_f2_supported(int n_dense, int dense_act, int dense_norm) {
+  return n_dense >= 1 && (dense_act == AMBER_ACT_RELU || dense_act == AMBER_ACT_LEAKYRELU) && dense_norm == AMBER_NORM_NONE;
+}
+
+template <int L, bool SPLIT, bool HEAD>
 static hipError_t launch_node_f2_t(const NodeArgs& a, int num_cus, hipStream_t s) {
   const int64_t ntiles = (a.N + kTile - 1) / kTile;
-  if (ntiles == 0 || (!a.do_update && !a.do_proj)) return hipSuccess;
-  const int P = (a.do_update ? a.nl + 1 : 0) + (a.do_proj ? 2 : 0);
+  if (ntiles == 0 || (!a.do_update && !a.do_proj && !HEAD)) return hipSuccess;
+  if (HEAD && (a.do_proj || a.n_dense < 1 || !a.do_readout)) return hipErrorInvalidValue;
+  const int P = (a.do_update ? a.nl + 1 : 0) + (a.do_proj ? 2 : 0) + (HEAD ? a.n_dense : 0);
   const size_t mat = static_cast<size_t>(L) * L * 4, wins = static_cast<size_t>(kF2Waves) * kWinBytes;
   const int resident = P * mat + wins <= 160 * 1024 ? 1 : 0;
   const size_t lds = (resident ? P : 2) * mat + wins;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(node_kernel_f2<L, SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(node_kernel_f2<L, SPLIT, HEAD>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      static_cast<int>(lds));
   if (e != hipSuccess) return e;
   int64_t grid = (num_cus / 8) * 8;  // one persistent workgroup per CU, a multiple of the 8 XCDs
   if (grid < 8) grid = 8;
-  hipLaunchKernelGGL((node_kernel_f2<L, SPLIT>), dim3(static_cast<unsigned>(grid)), dim3(kF2Block), lds, s, a, ntiles, resident);
+  hipLaunchKernelGGL((node_kernel_f2<L, SPLIT, HEAD>), dim3(static_cast<unsigned>(grid)), dim3(kF2Block), lds, s, a, ntiles, resident);
   return hipGetLastError();
 }
 
+template <int L>
+static hipError_t launch_node_f2_l(const NodeArgs& a, int num_cus, hipStream_t s) {
+  const bool head = a.do_readout != 0;  // the caller (run_node) clears the head fields unless it rides on this launch
+  if (a.single) return head ? launch_node_f2_t<L, false, true>(a, num_cus, s) : launch_node_f2_t<L, false, false>(a, num_cus, s);
+  return head ? launch_node_f2_t<L, true, true>(a, num_cus, s) : launch_node_f2_t<L, true, false>(a, num_cus, s);
+}
 hipError_t launch_node_f2(int L, const NodeArgs& a, int num_cus, hipStream_t s) {
   switch (L) {
-    case 32: return a.single ? launch_node_f2_t<32, false>(a, num_cus, s) : launch_node_f2_t<32, true>(a, num_cus, s);
-    case 64: return a.single ? launch_node_f2_t<64, false>(a, num_cus, s) : launch_node_f2_t<64, true>(a, num_cus, s);
-    case 128: return a.single ? launch_node_f2_t<128, false>(a, num_cus, s) : launch_node_f2_t<128, true>(a, num_cus, s);
+    case 32: return launch_node_f2_l<32>(a, num_cus, s);
+    case 64: return launch_node_f2_l<64>(a, num_cus, s);
+    case 128: return launch_node_f2_l<128>(a, num_cus, s);
     default: return hipErrorInvalidValue;
   }
 }

@@ -108,6 +108,7 @@ struct NodeArgs {
   // dense chain (decoder MLP or embedding MLP tail)
   int32_t n_dense;
   DenseLayer dense[kMaxLayers];
+  const float* dense_f2[kMaxLayers];  // the same matrices in the split-precision B-operand format, or nullptr (node_kernel_f2)
   int32_t dense_act;
   int32_t dense_norm;     // AMBER_NORM_*
   float* dense_out;       // [N,L] or nullptr
@@ -138,6 +139,8 @@ bool edge_f2_supported(int L, int nl, int act, int residual, int layer_norm);
 // feature-per-lane node kernel (update + next-step projections; weights as B operand, W0x / W0a sharing one scale)
 hipError_t launch_node_f2(int L, const NodeArgs& a, int num_cus, hipStream_t s);
 bool node_f2_supported(int L, int act, int residual, int layer_norm);
+// the split-precision node kernel can run the SupervisedMPN head (decoder layers as further phases + readout)
+bool head_f2_supported(int n_dense, int dense_act, int dense_norm);
 hipError_t launch_segment_mean(const float* vals, const int32_t* rowptr, int64_t N, int L, float* out, hipStream_t s);
 hipError_t launch_permute_rows(const float* in, const int32_t* perm, int64_t rows, int width, int gather, float* out,
                                hipStream_t s);

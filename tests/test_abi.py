@@ -47,8 +47,13 @@ def test_param_count_matches_survey_formula():
     assert lib.amber_mpn_param_floats(C.byref(d)) == 58944
     d = _desc(has_head=True, decoder_layers=2)
     assert lib.amber_mpn_param_floats(C.byref(d)) == 58944 + 2 * (64 * 64 + 64) + 64 + 1
-    # packed: per step 3 + 1 edge matrices, 2 + 1 node matrices; 2 decoder matrices; each L*L body + 8-float header
-    assert lib.amber_mpn_packed_floats(C.byref(d)) == (2 * 7 + 2) * (64 * 64 + 8)
+    # packed: per step 3 + 1 edge matrices, 2 + 1 node matrices; 2 decoder matrices in the exact format (stand-alone head,
+    # training) and, in the split-precision modes, 2 more in the format of the node launch the head rides on; each L*L body
+    # + 8-float header
+    heads = 4 if engine.default_precision != "fp32" else 2
+    assert lib.amber_mpn_packed_floats(C.byref(d)) == (2 * 7 + heads) * (64 * 64 + 8)
+    d32 = _desc(has_head=True, decoder_layers=2, precision="fp32")
+    assert lib.amber_mpn_packed_floats(C.byref(d32)) == (2 * 7 + 2) * (64 * 64 + 8)
 
 
 def test_descriptor_validation_reports_errors():
