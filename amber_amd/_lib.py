@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libamber_mpn.so")
+LIB_PATH = os.environ.get("AMBER_MPN_LIB") or os.path.join(_HERE, "csrc", "libamber_mpn.so")  # override: kernel experiments
 
 MAX_MLP_LAYERS = 4
 TILE = 32

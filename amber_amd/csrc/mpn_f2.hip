@@ -47,10 +47,19 @@ constexpr int kF2Block = 64 * kF2Waves;
 constexpr int kWinBytes = 4096;  // per-wave LDS window: hi plane [0, 2048), lo plane [2048, 4096)
 constexpr int kLoPlane = 2048;
 
+// max over the 64 lanes, result in every lane: DPP inside the rows of 16 lanes, then the row and half swaps of gfx950
+// (v_permlane16_swap / v_permlane32_swap) - no LDS round trips (ds_bpermute) and no lane-address registers, which the
+// compiler hoists out of the tile loop and spills
+#define AMBER_DPP_F(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, true))
 DEVINL float wave_max(float m) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-  return m;
+  m = fmaxf(m, AMBER_DPP_F(m, 0xB1));   // quad_perm [1,0,3,2]
+  m = fmaxf(m, AMBER_DPP_F(m, 0x4E));   // quad_perm [2,3,0,1]
+  m = fmaxf(m, AMBER_DPP_F(m, 0x141));  // row_half_mirror
+  m = fmaxf(m, AMBER_DPP_F(m, 0x140));  // row_mirror: every lane of a row of 16 holds the row's max
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(m), __float_as_uint(m), false, false);  // rows (0,0,2,2) | (1,1,3,3)
+  m = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  const auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);  // halves (lo,lo) | (hi,hi)
+  return fmaxf(__uint_as_float(q[0]), __uint_as_float(q[1]));
 }
 // power-of-two scale that brings m into [2^14, 2^15), and its inverse
 DEVINL void pow2_scale(float m, float& scale, float& inv) {
@@ -110,8 +119,10 @@ DEVINL float half_sum(float v) {
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));  // row_half_mirror
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));  // row_mirror
-  v += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));                   // lane ^ 16
-  return v;
+  // the other row of the half (lane ^ 16): v_permlane16_swap gives rows (0,0,2,2) and (1,1,3,3); the same two addends as
+  // a lane ^ 16 exchange, without the LDS round trip of ds_swizzle
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
 // transposing LDS read (ds_read_b64_tr_b16): per group of 16 lanes a block of 4 rows x 16 columns of 16-bit elements,
@@ -343,6 +354,37 @@ __global__ __launch_bounds__(kF2Block) void edge_kernel_f2(const EdgeArgs a, con
     load_idx(tile, s0, d0);
     if (tile + stride < t_end) load_idx(tile + stride, s1, d1);
   }
+  // Software pipeline over the tiles of a wave (PIPE): the rows of e that open a tile are loaded during the PREVIOUS
+  // tile's epilogue (LayerNorm, stores, per-destination sums), when the landing registers of the hidden layer are free,
+  // so their latency runs under that work.  Measured at L = 64: -2.4 % per launch.  At L = 128 the 64 loop-carried
+  // registers do not fit beside the accumulators (the kernel spills, and every scratch reload drains the in-order
+  // memory counter, prefetch included: +50 %), so the wide kernel keeps the loads at the top of the tile.
+  constexpr bool PIPE = !EMB && L <= 64;
+  ELanding<L> la;  // rows of e of the tile at hand: la.v[pass][it] = e[row it*8 + lane/8][32 pass + 4 (lane % 8) .. +3]
+  Tile<L> pn;      // P_s[src] of the tile at hand, accumulator layout (becomes the accumulator)
+  auto load_e = [&](int64_t t) {
+    const int64_t q0 = t * kTile;
+    const int lim = ((a.E - q0) < kTile ? static_cast<int>(a.E - q0) : kTile) - 1;
+    const float* const base = a.e + q0 * L;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int r = it * 8 + (lane >> 3);
+      const f32x4* p = reinterpret_cast<const f32x4*>(base + static_cast<unsigned>((r < lim ? r : lim) * L)) + (lane & 7);
+#pragma unroll
+      for (int ps = 0; ps < NFB; ++ps) la.v[ps][it] = p[ps * 8];
+    }
+  };
+  auto gather_ps = [&](int sidx) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int r = 8 * (i >> 2) + (i & 3) + 4 * h;
+      const int si = __shfl(sidx, r);
+      const float* ps = a.Ps + static_cast<int64_t>(DBG(32) ? 0 : si) * L + n;
+#pragma unroll
+      for (int fb = 0; fb < NFB; ++fb) pn.a[fb][i] = ps[32 * fb];
+    }
+  };
+  if (PIPE && tile < t_end) load_e(tile);
   for (; tile < t_end; tile += stride) {
     const int64_t p0 = tile * kTile;
     const int nvalid = (a.E - p0) < kTile ? static_cast<int>(a.E - p0) : kTile;  // >= 1: tile < ntiles
@@ -387,27 +429,11 @@ __global__ __launch_bounds__(kF2Block) void edge_kernel_f2(const EdgeArgs a, con
         }
       }
     };
-    // ---- streamed e rows (whole row pieces) ----
-    ELanding<L> la;
-    if constexpr (!EMB) {
-#pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int r = it * 8 + (lane >> 3);
-        const f32x4* p = reinterpret_cast<const f32x4*>(et + static_cast<unsigned>((r < rlim ? r : rlim) * L)) + (lane & 7);
-#pragma unroll
-        for (int ps = 0; ps < NFB; ++ps) la.v[ps][it] = p[ps * 8];
-      }
-    }
-    // ---- gathered first-layer terms, straight into the accumulator layout ----
-    Tile<L> acc;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int r = 8 * (i >> 2) + (i & 3) + 4 * h;
-      const int si = __shfl(s0, r);
-      const float* ps = a.Ps + static_cast<int64_t>(DBG(32) ? 0 : si) * L + n;
-#pragma unroll
-      for (int fb = 0; fb < NFB; ++fb) acc.a[fb][i] = ps[32 * fb];
-    }
+    // ---- streamed e rows (whole row pieces; PIPE: issued during the previous tile's epilogue) and gathered
+    // first-layer terms, straight into the accumulator layout ----
+    if constexpr (!EMB && !PIPE) load_e(tile);
+    gather_ps(s0);
+    Tile<L> acc = pn;
     int s2 = 0, d2 = 0;
     if (tile + 2 * stride < t_end) load_idx(tile + 2 * stride, s2, d2);
     const int firstd = __builtin_amdgcn_readlane(d0, 0);
@@ -478,6 +504,11 @@ __global__ __launch_bounds__(kF2Block) void edge_kernel_f2(const EdgeArgs a, con
 #pragma unroll
         for (int fb = 0; fb < NFB; ++fb) acc.a[fb][i] += et[off + 32 * fb];
       }
+    }
+    if constexpr (PIPE) {  // the next tile's opening loads, behind which the rest of this tile runs
+      __builtin_amdgcn_sched_barrier(0);  // not above the residual loads: their landing registers are free only now
+      if (tile + stride < t_end) load_e(tile + stride);
+      __builtin_amdgcn_sched_barrier(0);
     }
     // ---- LayerNorm over the features of every edge: across the lanes of a half, one register per edge ----
     if (a.layer_norm == AMBER_MODE_INNER && !DBG(64)) tile_layernorm_acc<L>(acc, a.gamma, a.beta, a.eps, n);
@@ -665,8 +696,10 @@ __global__ __launch_bounds__(kF2Block) void node_kernel_f2(const NodeArgs a, con
     const int nstore = mytile < t_end ? nvalid : 0;                              // rows this wave stores
     const int rlim = nvalid - 1;
     const float* const xt = a.x_in + n0 * L;
-    int hq = 4 * h * L + n, nq = n, lq = lane;
-    asm volatile("" : "+v"(hq), "+v"(nq), "+v"(lq));
+    // (h4: the row numbers 8 (i >> 2) + (i & 3) + 4 h of the 16 registers are cheaper to recompute than to keep -
+    // hoisted out of the loop they are spilled, and every scratch reload drains the in-order memory counter)
+    int hq = 4 * h * L + n, nq = n, lq = lane, h4 = 4 * h;
+    asm volatile("" : "+v"(hq), "+v"(nq), "+v"(lq), "+v"(h4));
     Tile<L> v;  // the tile's node features in accumulator layout (after the update: x')
     int k = 0;
     if (a.do_update) {
@@ -783,7 +816,7 @@ __global__ __launch_bounds__(kF2Block) void node_kernel_f2(const NodeArgs a, con
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const unsigned off = nvalid == kTile ? static_cast<unsigned>(hq + (8 * (i >> 2) + (i & 3)) * L)
-                                               : static_cast<unsigned>(min(8 * (i >> 2) + (i & 3) + 4 * h, rlim) * L + n);
+                                               : static_cast<unsigned>(min(8 * (i >> 2) + (i & 3) + h4, rlim) * L + n);
 #pragma unroll
           for (int fb = 0; fb < NFB; ++fb) acc.a[fb][i] += xt[off + 32 * fb];
         }
@@ -793,7 +826,7 @@ __global__ __launch_bounds__(kF2Block) void node_kernel_f2(const NodeArgs a, con
     } else {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const unsigned off = static_cast<unsigned>(min(8 * (i >> 2) + (i & 3) + 4 * h, rlim) * L + n);
+        const unsigned off = static_cast<unsigned>(min(8 * (i >> 2) + (i & 3) + h4, rlim) * L + n);
 #pragma unroll
         for (int fb = 0; fb < NFB; ++fb) v.a[fb][i] = xt[off + 32 * fb];
       }
@@ -811,7 +844,7 @@ __global__ __launch_bounds__(kF2Block) void node_kernel_f2(const NodeArgs a, con
       } else {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          if (8 * (i >> 2) + (i & 3) + 4 * h < nstore) {
+          if (8 * (i >> 2) + (i & 3) + h4 < nstore) {
 #pragma unroll
             for (int fb = 0; fb < NFB; ++fb) ot[static_cast<unsigned>(hq + (8 * (i >> 2) + (i & 3)) * L) + 32 * fb] = t.a[fb][i];
           }
@@ -838,7 +871,7 @@ __global__ __launch_bounds__(kF2Block) void node_kernel_f2(const NodeArgs a, con
           const float* const vt = (a.do_update ? a.x_out : a.x_in) + n0 * L;
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
-            const unsigned off = static_cast<unsigned>(min(8 * (i >> 2) + (i & 3) + 4 * h, rlim) * L + nq);
+            const unsigned off = static_cast<unsigned>(min(8 * (i >> 2) + (i & 3) + h4, rlim) * L + nq);
 #pragma unroll
             for (int fb = 0; fb < NFB; ++fb) v.a[fb][i] = vt[off + 32 * fb];
           }
@@ -890,7 +923,7 @@ __global__ __launch_bounds__(kF2Block) void node_kernel_f2(const NodeArgs a, con
 #pragma unroll
         for (int fb = 1; fb < NFB; ++fb) sacc = fmaf(v.a[fb][i], wq[fb], sacc);
         const float tot = half_sum(sacc) + br;
-        const int r = 8 * (i >> 2) + (i & 3) + 4 * h;
+        const int r = 8 * (i >> 2) + (i & 3) + h4;
         if (n == 0 && r < nstore) {
           const int64_t row = n0 + r;
           const int64_t oi = a.out_index ? static_cast<int64_t>(a.out_index[row]) : row;
