@@ -37,6 +37,10 @@
 #define DBG(bit) 0
 #endif
 
+#ifndef AMBER_NODE_RELOAD_V
+#define AMBER_NODE_RELOAD_V 0
+#endif
+
 namespace amber {
 
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
@@ -114,12 +118,18 @@ DEVINL void round4(const f32x4 x, float scale, half4& hi) {
   hi = __builtin_bit_cast(half4, hh);
 }
 // value that lane c (= tile row c) holds in `v`, for the row of accumulator register i in this lane's half: row
-// 8 (i >> 2) + (i & 3) + 4 h.  Two v_readlane (the rows are compile-time constants) and a select by half instead of a
-// ds_bpermute: no LDS round trip in front of every gathered row, and 13 registers fewer at L = 128.
+// 8 (i >> 2) + (i & 3) + 4 h.  L = 128: two v_readlane (the rows are compile-time constants) and a select by half
+// instead of a ds_bpermute - same time, 13 registers fewer (the fused-embedding variant stops spilling).  L <= 64, where
+// a row is only one or two loads, the scalar detour costs more than it saves (measured: +50 % per launch): ds_bpermute.
+template <int L>
 DEVINL int tile_row_value(int v, int i, int h) {
-  const int lo = __builtin_amdgcn_readlane(v, 8 * (i >> 2) + (i & 3));
-  const int hi = __builtin_amdgcn_readlane(v, 8 * (i >> 2) + (i & 3) + 4);
-  return h ? hi : lo;
+  if constexpr (L >= 128) {
+    const int lo = __builtin_amdgcn_readlane(v, 8 * (i >> 2) + (i & 3));
+    const int hi = __builtin_amdgcn_readlane(v, 8 * (i >> 2) + (i & 3) + 4);
+    return h ? hi : lo;
+  } else {
+    return __shfl(v, 8 * (i >> 2) + (i & 3) + 4 * h);
+  }
 }
 // sum over the 32 lanes of a half-wave, result in every lane of the half
 DEVINL float half_sum(float v) {
@@ -364,10 +374,10 @@ __global__ __launch_bounds__(kF2Block) void edge_kernel_f2(const EdgeArgs a, con
   }
   // Software pipeline over the tiles of a wave (PIPE): the rows of e that open a tile are loaded during the PREVIOUS
   // tile's epilogue (LayerNorm, stores, per-destination sums), when the landing registers of the hidden layer are free,
-  // so their latency runs under that work.  Measured at L = 64: -2.4 % per launch.  At L = 128 the 64 loop-carried
+  // so their latency runs under that work.  Measured at L = 64: -2.4 % per launch (L = 32: +30 %, off).  At L = 128 the 64 loop-carried
   // registers do not fit beside the accumulators (the kernel spills, and every scratch reload drains the in-order
   // memory counter, prefetch included: +50 %), so the wide kernel keeps the loads at the top of the tile.
-  constexpr bool PIPE = !EMB && L <= 64;
+  constexpr bool PIPE = !EMB && L == 64;
   ELanding<L> la;  // rows of e of the tile at hand: la.v[pass][it] = e[row it*8 + lane/8][32 pass + 4 (lane % 8) .. +3]
   Tile<L> pn;      // P_s[src] of the tile at hand, accumulator layout (becomes the accumulator)
   auto load_e = [&](int64_t t) {
@@ -385,7 +395,7 @@ __global__ __launch_bounds__(kF2Block) void edge_kernel_f2(const EdgeArgs a, con
   auto gather_ps = [&](int sidx) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      const int si = tile_row_value(sidx, i, h);
+      const int si = tile_row_value<L>(sidx, i, h);
       const float* ps = a.Ps + static_cast<int64_t>(DBG(32) ? 0 : si) * L + n;
 #pragma unroll
       for (int fb = 0; fb < NFB; ++fb) pn.a[fb][i] = ps[32 * fb];
@@ -425,7 +435,7 @@ __global__ __launch_bounds__(kF2Block) void edge_kernel_f2(const EdgeArgs a, con
       for (int i = 0; i < 16; ++i) {
         float ev[kMaxFusedEmbed];
 #pragma unroll
-        for (int k = 0; k < kMaxFusedEmbed; ++k) ev[k] = __int_as_float(tile_row_value(__float_as_int(eav[k]), i, h));
+        for (int k = 0; k < kMaxFusedEmbed; ++k) ev[k] = __int_as_float(tile_row_value<L>(__float_as_int(eav[k]), i, h));
 #pragma unroll
         for (int fb = 0; fb < NFB; ++fb) {
           float v = bq[fb];
@@ -469,7 +479,7 @@ __global__ __launch_bounds__(kF2Block) void edge_kernel_f2(const EdgeArgs a, con
       const float us = inv * wsinv0;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const int di = tile_row_value(d0, i, h);
+        const int di = tile_row_value<L>(d0, i, h);
         const float* pd = a.Pd + static_cast<int64_t>(DBG(2) ? 0 : di) * L + n;
 #pragma unroll
         for (int fb = 0; fb < NFB; ++fb) acc.a[fb][i] = fmaf(acc.a[fb][i], us, pd[32 * fb]);
@@ -549,7 +559,7 @@ __global__ __launch_bounds__(kF2Block) void edge_kernel_f2(const EdgeArgs a, con
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int r = 8 * (i >> 2) + (i & 3) + 4 * h;
-          const int orow = tile_row_value(pm, i, h);
+          const int orow = tile_row_value<L>(pm, i, h);
           if (r < nvalid) {
             float* po = a.out_edge + static_cast<int64_t>(orow) * L + n;
 #pragma unroll
@@ -871,9 +881,9 @@ __global__ __launch_bounds__(kF2Block) void node_kernel_f2(const NodeArgs a, con
       }
       {
         const unsigned char* wl = begin_phase(k++);
-        // x' again, from memory (this wave's own stores of a moment ago, or the input rows): kept in registers across
-        // the previous phase it would push the kernel over its 256 registers
-        {
+        // L = 128: x' again, from memory (this wave's own stores of a moment ago, or the input rows): kept in registers
+        // across the previous phase it would push the kernel over its 256 registers (432 bytes of scratch).  L <= 64: kept.
+        if constexpr (L > 64 || AMBER_NODE_RELOAD_V) {
           const float* const vt = (a.do_update ? a.x_out : a.x_in) + n0 * L;
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
