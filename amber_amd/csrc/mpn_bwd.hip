@@ -140,10 +140,13 @@ DEVINL void tile_colsum_acc(float* stage, const Tile<L>& t, float (&psum)[FPL], 
       for (int q = 0; q < FPL; ++q) psum[q] += stage[r * stage_stride<L>() + fo + q];
   }
 }
-// make this wave's global stores visible to its own later loads issued from other lanes
+// make this wave's global stores visible to its own later loads issued from other lanes.  Workgroup scope: the wave's
+// stores and loads go through the same vector L1, so ordering them (s_waitcnt) is enough.  Agent scope would be wrong
+// for the purpose and ruinous in cost: MI355X's L2s are per XCD, so an agent-scope release writes the whole XCD's dirty
+// L2 lines back and the acquire invalidates it - once per tile, that was 80 % of the backward's time.
 DEVINL void wave_global_handover() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
 // ---------------------------------------------------------------------------------------------------
