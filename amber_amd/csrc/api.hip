@@ -567,7 +567,7 @@ struct BwdWorkspace {
   size_t mat_floats;
   size_t bytes;
 };
-constexpr int kBwdMats = 12;
+constexpr int kBwdMats = 22;  // node 0..11 (2 + 2 per layer, plain / transposed), edge 12..19, projections^T 20, 21
 BwdWorkspace carve_bwd(const AmberMpnDesc& d, int64_t N, int64_t E, void* base) {
   const size_t L = static_cast<size_t>(d.latent);
   const size_t nb = align256(sizeof(float) * static_cast<size_t>(N) * L);
@@ -677,6 +677,10 @@ int backward_impl(const AmberMpnDesc* desc, const float* params, const float* pa
               "decoder weight gradient");
   }
 
+  // weight gradients of one module: one batched launch (+ one ordered reduction) over the module's matrices
+  auto wjob = [](WgradBatch& b, const float* A, const float* B, float* dW, int ld, int col0, float* db) {
+    b.job[b.n++] = WgradJob{A, B, dW, db, ld, col0};
+  };
   for (int it = iters - 1; it >= 0; --it) {
     const int step = it / d.num_step_repeats;
     const MlpLayout& mn = lay.node[step];
@@ -684,6 +688,35 @@ int backward_impl(const AmberMpnDesc* desc, const float* params, const float* pa
     const float* x_in = xbuf(it);
     const float* e_in = ebuf(it);
     const bool ln = d.layer_norm == AMBER_MODE_INNER;
+    // ---- the step's matrices in the exact operand order, plain and transposed: one launch ----
+    // slots: node W0x 0/1, W0a 2/3, W_l 2+2l / 3+2l;  edge W0e 12/13, W_l 12+2l / 13+2l;  W0s^T 20, W0d^T 21
+    {
+      PackBatch pb{};
+      auto pj = [&](const float* W, int ld, int col0, int slot, int transpose) {
+        pb.job[pb.n++] = PackJob{W, mat(slot), ld, col0, transpose};
+      };
+      pj(params + mn.W[0], 2 * L, 0, 0, 0);
+      pj(params + mn.W[0], 2 * L, 0, 1, 1);
+      pj(params + mn.W[0], 2 * L, L, 2, 0);
+      pj(params + mn.W[0], 2 * L, L, 3, 1);
+      for (int l = 1; l < nl; ++l) {
+        pj(params + mn.W[l], L, 0, 2 + 2 * l, 0);
+        pj(params + mn.W[l], L, 0, 3 + 2 * l, 1);
+      }
+      HIP_TRY(launch_pack_batch(L, pb, s), "pack node matrices");
+      if (E > 0) {
+        pb.n = 0;
+        pj(params + me.W[0], 3 * L, 2 * L, 12, 0);
+        pj(params + me.W[0], 3 * L, 2 * L, 13, 1);
+        for (int l = 1; l < nl; ++l) {
+          pj(params + me.W[l], L, 0, 12 + 2 * l, 0);
+          pj(params + me.W[l], L, 0, 13 + 2 * l, 1);
+        }
+        pj(params + me.W[0], 3 * L, 0, 20, 1);
+        pj(params + me.W[0], 3 * L, L, 21, 1);
+        HIP_TRY(launch_pack_batch(L, pb, s), "pack edge matrices");
+      }
+    }
     // ---- node module: x' = LN(MLP([x, mean(e')]) + x) ----
     if (E > 0)
       HIP_TRY(launch_segment_reduce(ebuf(it + 1), rowptr, nullptr, N, L, 1, w.M, s), "mean aggregate");
@@ -701,18 +734,12 @@ int backward_impl(const AmberMpnDesc* desc, const float* params, const float* pa
       a.layer_norm = d.layer_norm;
       a.gamma = ln ? params + lay.ng[step] : nullptr;
       a.eps = d.ln_eps;
-      HIP_TRY(launch_pack(L, params + mn.W[0], 2 * L, 0, mat(0), s), "pack W0x");
-      HIP_TRY(launch_pack_t(L, params + mn.W[0], 2 * L, 0, mat(1), s), "pack W0x^T");
-      HIP_TRY(launch_pack(L, params + mn.W[0], 2 * L, L, mat(2), s), "pack W0a");
-      HIP_TRY(launch_pack_t(L, params + mn.W[0], 2 * L, L, mat(3), s), "pack W0a^T");
       a.w_in = mat(0);
       a.wT_in = mat(1);
       a.w_m = mat(2);
       a.wT_m = mat(3);
       a.b0 = params + mn.B[0];
       for (int l = 1; l < nl; ++l) {
-        HIP_TRY(launch_pack(L, params + mn.W[l], L, 0, mat(2 + 2 * l), s), "pack node W_l");
-        HIP_TRY(launch_pack_t(L, params + mn.W[l], L, 0, mat(3 + 2 * l), s), "pack node W_l^T");
         a.layers[l] = DenseLayer{mat(2 + 2 * l), params + mn.B[l], nullptr, nullptr};
         a.wT[l] = mat(3 + 2 * l);
       }
@@ -725,10 +752,12 @@ int backward_impl(const AmberMpnDesc* desc, const float* params, const float* pa
       a.part = ln ? w.lnpart : nullptr;
       HIP_TRY(launch_chain_bwd(L, a, s), "node backward kernel");
       if (ln) HIP_TRY(launch_colpart_reduce(w.lnpart, gn, L, g + lay.ng[step], L, g + lay.nb[step], L, s), "node LayerNorm gradient");
-      HIP_TRY(launch_wgrad(L, w.DHN[0], x_in, N, g + mn.W[0], 2 * L, 0, g + mn.B[0], w.gpart, w.cpart, s), "dW0x");
-      HIP_TRY(launch_wgrad(L, w.DHN[0], w.M, N, g + mn.W[0], 2 * L, L, nullptr, w.gpart, w.cpart, s), "dW0a");
-      for (int l = 1; l < nl; ++l)
-        HIP_TRY(launch_wgrad(L, w.DHN[l], w.AN[l - 1], N, g + mn.W[l], L, 0, g + mn.B[l], w.gpart, w.cpart, s), "node dW_l");
+      WgradBatch wb{};
+      wb.M = N;
+      wjob(wb, w.DHN[0], x_in, g + mn.W[0], 2 * L, 0, g + mn.B[0]);  // dW0x, db0
+      wjob(wb, w.DHN[0], w.M, g + mn.W[0], 2 * L, L, nullptr);       // dW0a
+      for (int l = 1; l < nl; ++l) wjob(wb, w.DHN[l], w.AN[l - 1], g + mn.W[l], L, 0, g + mn.B[l]);
+      HIP_TRY(launch_wgrad_batch(L, wb, w.gpart, w.cpart, s), "node weight gradients");
     }
     if (E == 0) continue;
     // ---- edge module: e' = LN(MLP([x_s, x_d, e]) + e), first layer split into P_s[src] + P_d[dst] + W0e e ----
@@ -753,15 +782,11 @@ int backward_impl(const AmberMpnDesc* desc, const float* params, const float* pa
       a.layer_norm = d.layer_norm;
       a.gamma = ln ? params + lay.eg[step] : nullptr;
       a.eps = d.ln_eps;
-      HIP_TRY(launch_pack(L, params + me.W[0], 3 * L, 2 * L, mat(0), s), "pack W0e");
-      HIP_TRY(launch_pack_t(L, params + me.W[0], 3 * L, 2 * L, mat(1), s), "pack W0e^T");
-      a.w_in = mat(0);
-      a.wT_in = mat(1);
+      a.w_in = mat(12);
+      a.wT_in = mat(13);
       for (int l = 1; l < nl; ++l) {
-        HIP_TRY(launch_pack(L, params + me.W[l], L, 0, mat(2 * l), s), "pack edge W_l");
-        HIP_TRY(launch_pack_t(L, params + me.W[l], L, 0, mat(2 * l + 1), s), "pack edge W_l^T");
-        a.layers[l] = DenseLayer{mat(2 * l), params + me.B[l], nullptr, nullptr};
-        a.wT[l] = mat(2 * l + 1);
+        a.layers[l] = DenseLayer{mat(12 + 2 * l), params + me.B[l], nullptr, nullptr};
+        a.wT[l] = mat(13 + 2 * l);
       }
       for (int l = 0; l < nl; ++l) {
         a.A[l] = w.AE[l];
@@ -772,17 +797,20 @@ int backward_impl(const AmberMpnDesc* desc, const float* params, const float* pa
       a.part = ln ? w.lnpart : nullptr;
       HIP_TRY(launch_chain_bwd(L, a, s), "edge backward kernel");
       if (ln) HIP_TRY(launch_colpart_reduce(w.lnpart, ge, L, g + lay.eg[step], L, g + lay.eb[step], L, s), "edge LayerNorm gradient");
-      HIP_TRY(launch_wgrad(L, w.DHE[0], e_in, E, g + me.W[0], 3 * L, 2 * L, nullptr, w.gpart, w.cpart, s), "dW0e");
-      for (int l = 1; l < nl; ++l)
-        HIP_TRY(launch_wgrad(L, w.DHE[l], w.AE[l - 1], E, g + me.W[l], L, 0, g + me.B[l], w.gpart, w.cpart, s), "edge dW_l");
+      WgradBatch we{};
+      we.M = E;
+      wjob(we, w.DHE[0], e_in, g + me.W[0], 3 * L, 2 * L, nullptr);  // dW0e
+      for (int l = 1; l < nl; ++l) wjob(we, w.DHE[l], w.AE[l - 1], g + me.W[l], L, 0, g + me.B[l]);
+      HIP_TRY(launch_wgrad_batch(L, we, w.gpart, w.cpart, s), "edge weight gradients");
       // gathered first-layer terms: gradients summed per destination (CSR rows) and per source (source-sorted order)
       HIP_TRY(launch_segment_reduce(w.DHE[0], rowptr, nullptr, N, L, 0, w.dPd, s), "dP_d");
       HIP_TRY(launch_segment_reduce(w.DHE[0], rowptr_src, perm_src, N, L, 0, w.dPs, s), "dP_s");
-      HIP_TRY(launch_wgrad(L, w.dPs, x_in, N, g + me.W[0], 3 * L, 0, nullptr, w.gpart, w.cpart, s), "dW0s");
-      HIP_TRY(launch_wgrad(L, w.dPd, x_in, N, g + me.W[0], 3 * L, L, g + me.B[0], w.gpart, w.cpart, s), "dW0d");
-      HIP_TRY(launch_pack_t(L, params + me.W[0], 3 * L, 0, mat(10), s), "pack W0s^T");
-      HIP_TRY(launch_pack_t(L, params + me.W[0], 3 * L, L, mat(11), s), "pack W0d^T");
-      HIP_TRY(launch_rows_gemm_add(L, w.dX, w.dPs, mat(10), w.dPd, mat(11), N, s), "dx from the projections");
+      WgradBatch wp{};
+      wp.M = N;
+      wjob(wp, w.dPs, x_in, g + me.W[0], 3 * L, 0, nullptr);       // dW0s
+      wjob(wp, w.dPd, x_in, g + me.W[0], 3 * L, L, g + me.B[0]);   // dW0d, db0
+      HIP_TRY(launch_wgrad_batch(L, wp, w.gpart, w.cpart, s), "projection weight gradients");
+      HIP_TRY(launch_rows_gemm_add(L, w.dX, w.dPs, mat(20), w.dPd, mat(21), N, s), "dx from the projections");
     }
   }
   // ---- input embeddings (src/mpn/input_embedding.py:41-42) ----

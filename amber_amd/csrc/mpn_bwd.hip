@@ -378,9 +378,16 @@ struct WgradCfg {
   static constexpr size_t lds_bytes() { return sizeof(float) * (static_cast<size_t>(S - 1) * GROUPS * (TILE_FLOATS + TA * 32)); }
 };
 
+// blockIdx.y selects the job of a batch (products over the same rows M: the weight matrices of one module)
 template <int L>
-__global__ __launch_bounds__(512) void wgrad_kernel(const float* __restrict__ A, const float* __restrict__ B, int64_t M, int64_t chunk,
-                                                    float* __restrict__ part, float* __restrict__ cpart) {
+__global__ __launch_bounds__(512) void wgrad_kernel(const WgradBatch jobs, int64_t chunk, float* __restrict__ part_all,
+                                                    float* __restrict__ cpart_all) {
+  const WgradJob jb = jobs.job[blockIdx.y];
+  const float* __restrict__ A = jb.A;
+  const float* __restrict__ B = jb.B;
+  const int64_t M = jobs.M;
+  float* __restrict__ part = part_all + static_cast<int64_t>(blockIdx.y) * gridDim.x * L * L;
+  float* __restrict__ cpart = jb.db ? cpart_all + static_cast<int64_t>(blockIdx.y) * gridDim.x * L : nullptr;
   using C = WgradCfg<L>;
   constexpr int VEC = C::VEC, TA = C::TA, GROUPS = C::GROUPS, S = C::S, U = 8;
   typedef typename VecOf<VEC>::type vecf;
@@ -485,14 +492,17 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const float* __restrict__ A,
     for (int ta = 0; ta < TA; ++ta) cpart[static_cast<int64_t>(blockIdx.x) * L + VEC * c + TA * grp + ta] = cs[ta];
   }
 }
-// dW[o][col0 + k] += sum_g part[g][o][k];  db[o] += sum_g cpart[g][o].  A workgroup takes 64 consecutive outputs and
-// four interleaved subsequences of g, combined in a fixed order (deterministic).
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ cpart, int G, int L,
-                                                           float* __restrict__ dW, int ld, int col0, float* __restrict__ db) {
+// dW[o][col0 + k] += sum_g part[g][o][k];  db[o] += sum_g cpart[g][o], per job (blockIdx.y).  A workgroup takes 64
+// consecutive outputs and four interleaved subsequences of g, combined in a fixed order (deterministic).
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradBatch jobs, const float* __restrict__ part_all,
+                                                           const float* __restrict__ cpart_all, int G, int L) {
   __shared__ float sm[4][64];
-  const int i = blockIdx.x * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
+  const WgradJob jb = jobs.job[blockIdx.y];
   const int LL = L * L;
-  const bool is_w = i < LL, is_b = !is_w && i < LL + L && db && cpart;
+  const float* part = part_all + static_cast<int64_t>(blockIdx.y) * G * LL;
+  const float* cpart = cpart_all + static_cast<int64_t>(blockIdx.y) * G * L;
+  const int i = blockIdx.x * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
+  const bool is_w = i < LL, is_b = !is_w && i < LL + L && jb.db;
   float s = 0.f;
   if (is_w) {
     for (int g = sl; g < G; g += 4) s += part[static_cast<int64_t>(g) * LL + i];
@@ -505,9 +515,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     const int t = threadIdx.x;
     const float tot = ((sm[0][t] + sm[1][t]) + sm[2][t]) + sm[3][t];
     if (is_w)
-      dW[static_cast<int64_t>(i / L) * ld + col0 + (i % L)] += tot;
+      jb.dW[static_cast<int64_t>(i / L) * jb.ld + jb.col0 + (i % L)] += tot;
     else if (is_b)
-      db[i - LL] += tot;
+      jb.db[i - LL] += tot;
   }
 }
 
@@ -608,6 +618,28 @@ __global__ void pack_t_kernel(const float* __restrict__ W, int ld, int col0, flo
   reinterpret_cast<f32x4*>(out)[i] = v;
 }
 
+// The matrices one backward step needs, re-tiled in one launch: blockIdx.y selects the job; plain (pack_kernel order) or
+// transposed (pack_t_kernel order) tiles of columns [col0, col0 + L) of W[L, ld]
+template <int L>
+__global__ void pack_batch_kernel(const PackBatch jobs) {
+  constexpr int NFB = L / 32;
+  const PackJob jb = jobs.job[blockIdx.y];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // float4 index
+  if (i >= L * L / 4) return;
+  const int lane = i & 63, fb = (i >> 6) % NFB, j = (i >> 6) / NFB;
+  const int r = 32 * fb + (lane & 31), k0 = 8 * j + 4 * (lane >> 5);
+  f32x4 v;
+  if (jb.transpose) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) v[t] = jb.W[static_cast<int64_t>(k0 + t) * jb.ld + jb.col0 + r];
+  } else {
+    const float* src = jb.W + static_cast<int64_t>(r) * jb.ld + jb.col0 + k0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) v[t] = src[t];
+  }
+  reinterpret_cast<f32x4*>(jb.out)[i] = v;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------------
@@ -639,8 +671,9 @@ hipError_t launch_colpart_reduce(const float* part, int G, int L, float* out0, i
   return hipGetLastError();
 }
 
-int wgrad_chunks(int64_t M, int64_t* chunk_out) {
-  int64_t chunk = cdiv(cdiv(M, kWgradMaxChunks), 16) * 16;
+int wgrad_chunks(int64_t M, int njobs, int64_t* chunk_out) {
+  const int maxg = kWgradMaxChunks / (njobs < 1 ? 1 : njobs);  // the partial buffers hold kWgradMaxChunks products in all
+  int64_t chunk = cdiv(cdiv(M, maxg), 16) * 16;
   if (chunk < 256) chunk = 256;
   int64_t G = cdiv(M, chunk);
   if (G < 1) G = 1;
@@ -648,29 +681,36 @@ int wgrad_chunks(int64_t M, int64_t* chunk_out) {
   return static_cast<int>(G);
 }
 template <int L>
-static hipError_t launch_wgrad_t(const float* A, const float* B, int64_t M, float* dW, int ld, int col0, float* db, float* part,
-                                 float* cpart, hipStream_t s) {
+static hipError_t launch_wgrad_t(const WgradBatch& b, float* part, float* cpart, hipStream_t s) {
   int64_t chunk = 0;
-  const int G = wgrad_chunks(M, &chunk);
+  const int G = wgrad_chunks(b.M, b.n, &chunk);
   const size_t lds = WgradCfg<L>::lds_bytes();
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<L>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      static_cast<int>(lds));
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(wgrad_kernel<L>, dim3(G), dim3(512), lds, s, A, B, M, chunk, part, db ? cpart : nullptr);
+  hipLaunchKernelGGL(wgrad_kernel<L>, dim3(G, b.n), dim3(512), lds, s, b, chunk, part, cpart);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(L * L + L, 64)), dim3(256), 0, s, part, db ? cpart : nullptr, G, L, dW, ld, col0, db);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(L * L + L, 64), b.n), dim3(256), 0, s, b, part, cpart, G, L);
   return hipGetLastError();
+}
+hipError_t launch_wgrad_batch(int L, const WgradBatch& b, float* part, float* cpart, hipStream_t s) {
+  if (b.M == 0 || b.n == 0) return hipSuccess;
+  if (b.n > kWgradMaxJobs) return hipErrorInvalidValue;
+  switch (L) {
+    case 32: return launch_wgrad_t<32>(b, part, cpart, s);
+    case 64: return launch_wgrad_t<64>(b, part, cpart, s);
+    case 128: return launch_wgrad_t<128>(b, part, cpart, s);
+    default: return hipErrorInvalidValue;
+  }
 }
 hipError_t launch_wgrad(int L, const float* A, const float* B, int64_t M, float* dW, int ld, int col0, float* db, float* part,
                         float* cpart, hipStream_t s) {
-  if (M == 0) return hipSuccess;
-  switch (L) {
-    case 32: return launch_wgrad_t<32>(A, B, M, dW, ld, col0, db, part, cpart, s);
-    case 64: return launch_wgrad_t<64>(A, B, M, dW, ld, col0, db, part, cpart, s);
-    case 128: return launch_wgrad_t<128>(A, B, M, dW, ld, col0, db, part, cpart, s);
-    default: return hipErrorInvalidValue;
-  }
+  WgradBatch b{};
+  b.n = 1;
+  b.M = M;
+  b.job[0] = WgradJob{A, B, dW, db, ld, col0};
+  return launch_wgrad_batch(L, b, part, cpart, s);
 }
 
 int embed_bwd_chunks(int64_t rows, int64_t* chunk_out) {
@@ -720,6 +760,22 @@ hipError_t launch_rows_gemm_add(int L, float* io, const float* in0, const float*
     case 32: return launch_rows_gemm_add_t<32>(io, in0, w0, in1, w1, rows, s);
     case 64: return launch_rows_gemm_add_t<64>(io, in0, w0, in1, w1, rows, s);
     case 128: return launch_rows_gemm_add_t<128>(io, in0, w0, in1, w1, rows, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+template <int L>
+static hipError_t launch_pack_batch_t(const PackBatch& b, hipStream_t s) {
+  hipLaunchKernelGGL(pack_batch_kernel<L>, dim3(cdiv(L * L / 4, 256), b.n), dim3(256), 0, s, b);
+  return hipGetLastError();
+}
+hipError_t launch_pack_batch(int L, const PackBatch& b, hipStream_t s) {
+  if (b.n == 0) return hipSuccess;
+  if (b.n > kPackMaxJobs) return hipErrorInvalidValue;
+  switch (L) {
+    case 32: return launch_pack_batch_t<32>(b, s);
+    case 64: return launch_pack_batch_t<64>(b, s);
+    case 128: return launch_pack_batch_t<128>(b, s);
     default: return hipErrorInvalidValue;
   }
 }

@@ -187,10 +187,36 @@ struct ChainBwdArgs {
 int chain_bwd_grid(int64_t rows);
 hipError_t launch_chain_bwd(int L, const ChainBwdArgs& a, hipStream_t s);
 hipError_t launch_colpart_reduce(const float* part, int G, int L, float* out0, int n0, float* out1, int n1, hipStream_t s);
-int wgrad_chunks(int64_t M, int64_t* chunk_out);
+// weight-gradient products over the same rows, one launch (the matrices of one module)
+constexpr int kWgradMaxJobs = 6;
+struct WgradJob {
+  const float* A;   // [M,L] gradient at the layer's pre-activation
+  const float* B;   // [M,L] the layer's input
+  float* dW;        // dW[:, col0:col0+L] += A^T B, leading dimension ld
+  float* db;        // db += column sums of A, or nullptr
+  int32_t ld, col0;
+};
+struct WgradBatch {
+  WgradJob job[kWgradMaxJobs];
+  int32_t n;
+  int64_t M;
+};
+int wgrad_chunks(int64_t M, int njobs, int64_t* chunk_out);
+hipError_t launch_wgrad_batch(int L, const WgradBatch& b, float* part, float* cpart, hipStream_t s);
 // dW[:, col0:col0+L] += A^T B (A, B: [M,L]); db += column sums of A (db may be nullptr)
 hipError_t launch_wgrad(int L, const float* A, const float* B, int64_t M, float* dW, int ld, int col0, float* db, float* part,
                         float* cpart, hipStream_t s);
+constexpr int kPackMaxJobs = 16;
+struct PackJob {
+  const float* W;
+  float* out;
+  int32_t ld, col0, transpose;
+};
+struct PackBatch {
+  PackJob job[kPackMaxJobs];
+  int32_t n;
+};
+hipError_t launch_pack_batch(int L, const PackBatch& b, hipStream_t s);
 int embed_bwd_chunks(int64_t rows, int64_t* chunk_out);
 hipError_t launch_embed_bwd(int L, const float* d, const float* raw, const int32_t* perm, int64_t rows, int F, float* dW, float* db,
                             float* part, hipStream_t s);
