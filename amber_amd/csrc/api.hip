@@ -860,9 +860,27 @@ int amber_mpn_pack_weights(const AmberMpnDesc* desc, const float* params, float*
   // edge and node kernels).  `f0[cb]` is the format of column block cb of layer 0, `share0` makes its FMT_F2 blocks
   // share one power-of-two scale (they feed one accumulator), `frest` is the format of layers >= 1.
   enum { FMT_F32 = 0, FMT_F2 = 2 };
+  // the matrices are queued and re-tiled in batched launches (a training step packs ~150 matrices after every
+  // optimizer step: one launch each would be ~450 tiny kernels)
+  F2PackBatch q2{};
+  PackBatch q32{};
+  auto flush = [&]() -> hipError_t {
+    hipError_t e = launch_pack_f2_batch(L, q2, s);
+    q2.n = 0;
+    if (e != hipSuccess) return e;
+    e = launch_pack_batch(L, q32, s);
+    q32.n = 0;
+    return e;
+  };
   auto pack_one = [&](int fmt, const float* W, int ld, int col0, int scol0, int scols, float* out) -> hipError_t {
-    if (fmt == FMT_F2) return launch_pack_f2(L, W, ld, col0, scol0, scols, out, s);
-    return launch_pack(L, W, ld, col0, out, s);
+    if (fmt == FMT_F2) {
+      q2.job[q2.n++] = F2PackJob{W, out, ld, col0, scol0, scols};
+      if (q2.n == kF2PackMaxJobs) return flush();
+    } else {
+      q32.job[q32.n++] = PackJob{W, out, ld, col0, 0};
+      if (q32.n == kPackMaxJobs) return flush();
+    }
+    return hipSuccess;
   };
   auto pack_mlp = [&](const MlpLayout& m, int blocks0, int f00 = FMT_F32, int f01 = FMT_F32, int f02 = FMT_F32, bool share0 = false,
                       int frest = FMT_F32) -> hipError_t {
@@ -893,8 +911,9 @@ int amber_mpn_pack_weights(const AmberMpnDesc* desc, const float* params, float*
     HIP_TRY(pack_mlp(lay.dec, 1), "pack decoder");
     for (int l = 0; l < desc->decoder_layers; ++l)
       if (lay.dec_f2[l] >= 0)
-        HIP_TRY(launch_pack_f2(L, params + lay.dec.W[l], L, 0, 0, L, packed + lay.dec_f2[l], s), "pack decoder (split precision)");
+        HIP_TRY(pack_one(FMT_F2, params + lay.dec.W[l], L, 0, 0, L, packed + lay.dec_f2[l]), "pack decoder (split precision)");
   }
+  HIP_TRY(flush(), "pack weights");
   return AMBER_OK;
 }
 

@@ -954,30 +954,43 @@ __global__ __launch_bounds__(kF2Block) void node_kernel_f2(const NodeArgs a, con
 // ---------------------------------------------------------------------------------------------------
 // weight packing: absmax -> power-of-two scale -> hi/lo fp16 in B-operand order (+ header)
 // ---------------------------------------------------------------------------------------------------
-__global__ void absmax_f2_kernel(const float* __restrict__ W, int ld, int col0, int ncols, int L, unsigned* __restrict__ out_bits) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= L * ncols) return;
-  const float v = fabsf(W[static_cast<int64_t>(i / ncols) * ld + col0 + (i % ncols)]);
-  atomicMax(out_bits, __float_as_uint(v));  // non-negative floats order like their bit patterns; integer atomic
-}
-
 // out: [s][fb][hi|lo][lane][8 halves]; element j of lane (h, r) is W[32 fb + r][col0 + 16 s + 8 h + j];
 // header (8 floats after the L*L*4 body bytes): [0] = inverse scale, [1] = scale
+// Batched form (one launch pair for many matrices; a training step re-tiles every matrix after each optimizer step):
+// a workgroup per job finds max|W| over the job's scale columns (max is order-independent: no atomics needed),
 template <int L>
-__global__ void pack_f2_kernel(const float* __restrict__ W, int ld, int col0, float* __restrict__ out,
-                               const unsigned* __restrict__ absmax_bits) {
+__global__ __launch_bounds__(256) void absmax_f2_batch_kernel(const F2PackBatch jobs) {
+  __shared__ unsigned red[256];
+  const F2PackJob jb = jobs.job[blockIdx.x];
+  unsigned m = 0u;
+  for (int i = threadIdx.x; i < L * jb.scale_cols; i += 256) {
+    const unsigned v = __float_as_uint(fabsf(jb.W[static_cast<int64_t>(i / jb.scale_cols) * jb.ld + jb.scale_col0 + (i % jb.scale_cols)]));
+    m = v > m ? v : m;  // non-negative floats order like their bit patterns
+  }
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (int o = 128; o >= 1; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] = red[threadIdx.x] > red[threadIdx.x + o] ? red[threadIdx.x] : red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) reinterpret_cast<unsigned*>(jb.out + L * L + 4)[0] = red[0];  // scratch word inside the header
+}
+// and blockIdx.y selects the job of the re-tiling kernel proper
+template <int L>
+__global__ void pack_f2_batch_kernel(const F2PackBatch jobs) {
+  const F2PackJob jb = jobs.job[blockIdx.y];
   constexpr int NFB = L / 32, NS = L / 16;
-  int ex = static_cast<int>((*absmax_bits >> 23) & 0xffu);
+  int ex = static_cast<int>((reinterpret_cast<const unsigned*>(jb.out + L * L + 4)[0] >> 23) & 0xffu);
   ex = ex < kMinScaleExp ? kMinScaleExp : ex;
   const float scale = __uint_as_float(static_cast<unsigned>(268 - ex) << 23);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;  // (s, fb, lane)
   if (i == 0) {
-    out[L * L + 0] = __uint_as_float(static_cast<unsigned>(ex - 14) << 23);
-    out[L * L + 1] = scale;
+    jb.out[L * L + 0] = __uint_as_float(static_cast<unsigned>(ex - 14) << 23);
+    jb.out[L * L + 1] = scale;
   }
   if (i >= NS * NFB * 64) return;
   const int lane = i & 63, fb = (i >> 6) % NFB, s = (i >> 6) / NFB;
-  const float* src = W + static_cast<int64_t>(32 * fb + (lane & 31)) * ld + col0 + 16 * s + 8 * (lane >> 5);
+  const float* src = jb.W + static_cast<int64_t>(32 * fb + (lane & 31)) * jb.ld + jb.col0 + 16 * s + 8 * (lane >> 5);
   half8 hi, lo;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -986,28 +999,32 @@ __global__ void pack_f2_kernel(const float* __restrict__ W, int ld, int col0, fl
     hi[j] = hh;
     lo[j] = static_cast<_Float16>(ws - static_cast<float>(hh));
   }
-  half8* o = reinterpret_cast<half8*>(out);
+  half8* o = reinterpret_cast<half8*>(jb.out);
   o[((s * NFB + fb) * 2 + 0) * 64 + lane] = hi;
   o[((s * NFB + fb) * 2 + 1) * 64 + lane] = lo;
 }
 
 template <int L>
-static hipError_t launch_pack_f2_t(const float* W, int ld, int col0, int scale_col0, int scale_cols, float* out, hipStream_t s) {
-  unsigned* bits = reinterpret_cast<unsigned*>(out + L * L + 4);  // scratch word inside the header
-  hipError_t e = hipMemsetAsync(bits, 0, sizeof(unsigned), s);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(absmax_f2_kernel, dim3((L * scale_cols + 255) / 256), dim3(256), 0, s, W, ld, scale_col0, scale_cols, L, bits);
-  hipLaunchKernelGGL(pack_f2_kernel<L>, dim3((L / 16 * (L / 32) * 64 + 255) / 256), dim3(256), 0, s, W, ld, col0, out, bits);
+static hipError_t launch_pack_f2_batch_t(const F2PackBatch& b, hipStream_t s) {
+  hipLaunchKernelGGL(absmax_f2_batch_kernel<L>, dim3(b.n), dim3(256), 0, s, b);
+  hipLaunchKernelGGL(pack_f2_batch_kernel<L>, dim3((L / 16 * (L / 32) * 64 + 255) / 256, b.n), dim3(256), 0, s, b);
   return hipGetLastError();
 }
-
-hipError_t launch_pack_f2(int L, const float* W, int ld, int col0, int scale_col0, int scale_cols, float* out, hipStream_t s) {
+hipError_t launch_pack_f2_batch(int L, const F2PackBatch& b, hipStream_t s) {
+  if (b.n == 0) return hipSuccess;
+  if (b.n > kF2PackMaxJobs) return hipErrorInvalidValue;
   switch (L) {
-    case 32: return launch_pack_f2_t<32>(W, ld, col0, scale_col0, scale_cols, out, s);
-    case 64: return launch_pack_f2_t<64>(W, ld, col0, scale_col0, scale_cols, out, s);
-    case 128: return launch_pack_f2_t<128>(W, ld, col0, scale_col0, scale_cols, out, s);
+    case 32: return launch_pack_f2_batch_t<32>(b, s);
+    case 64: return launch_pack_f2_batch_t<64>(b, s);
+    case 128: return launch_pack_f2_batch_t<128>(b, s);
     default: return hipErrorInvalidValue;
   }
+}
+hipError_t launch_pack_f2(int L, const float* W, int ld, int col0, int scale_col0, int scale_cols, float* out, hipStream_t s) {
+  F2PackBatch b{};
+  b.n = 1;
+  b.job[0] = F2PackJob{W, out, ld, col0, scale_col0, scale_cols};
+  return launch_pack_f2_batch(L, b, s);
 }
 
 size_t edge_f2_lds_bytes(int L, int nl) {

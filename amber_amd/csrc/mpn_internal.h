@@ -133,6 +133,17 @@ hipError_t launch_pack(int L, const float* W, int ld, int col0, float* out, hipS
 // A packed matrix is L*L floats of body + kPackedHeader floats (split-precision formats keep their scales there).
 constexpr int kPackedHeader = 8;
 // feature-per-lane split-precision edge kernel, mpn_f2.hip (weights as B operand: launch_pack_f2)
+constexpr int kF2PackMaxJobs = 24;
+struct F2PackJob {
+  const float* W;   // [L, ld]
+  float* out;       // packed matrix + header
+  int32_t ld, col0, scale_col0, scale_cols;
+};
+struct F2PackBatch {
+  F2PackJob job[kF2PackMaxJobs];
+  int32_t n;
+};
+hipError_t launch_pack_f2_batch(int L, const F2PackBatch& b, hipStream_t s);
 hipError_t launch_pack_f2(int L, const float* W, int ld, int col0, int scale_col0, int scale_cols, float* out, hipStream_t s);
 hipError_t launch_edge_f2(int L, const EdgeArgs& a, int num_cus, hipStream_t s);
 bool edge_f2_supported(int L, int nl, int act, int residual, int layer_norm);
