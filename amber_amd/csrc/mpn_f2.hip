@@ -47,7 +47,29 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
 
 constexpr int kF2Waves = 8;
-constexpr int kF2Block = 64 * kF2Waves;
+#ifndef AMBER_EDGE_WAVES_64
+#define AMBER_EDGE_WAVES_64 12
+#endif
+#ifndef AMBER_EDGE_WAVES_32
+#define AMBER_EDGE_WAVES_32 16
+#endif
+// Waves per workgroup (= per CU) of the edge kernel.  L = 64: 12 (three per SIMD; the kernel fits 168 registers without
+// the tile pipeline): -8 % per launch against 8 waves.  L = 32: 16 (four per SIMD): -22 %.  L = 128: 8 - registers (acc 64 + landing 64 + operands 48) and
+// LDS (2 x 64 KB weights + 4 KB window a wave) allow no third wave.
+#ifndef AMBER_NODE_WAVES_64
+#define AMBER_NODE_WAVES_64 12
+#endif
+#ifndef AMBER_NODE_WAVES_32
+#define AMBER_NODE_WAVES_32 16
+#endif
+template <int L>
+constexpr int node_waves() {
+  return L == 64 ? AMBER_NODE_WAVES_64 : (L == 32 ? AMBER_NODE_WAVES_32 : kF2Waves);
+}
+template <int L>
+constexpr int edge_waves() {
+  return L == 64 ? AMBER_EDGE_WAVES_64 : (L == 32 ? AMBER_EDGE_WAVES_32 : kF2Waves);
+}
 constexpr int kWinBytes = 4096;  // per-wave LDS window: hi plane [0, 2048), lo plane [2048, 4096)
 constexpr int kLoPlane = 2048;
 
@@ -331,7 +353,7 @@ DEVINL void tile_layernorm_acc(Tile<L>& acc, const float* __restrict__ gamma, co
 
 // EMB: first step with the linear edge embedding fused in (e is computed on the fly instead of read)
 template <int L, bool EMB, bool SPLIT>
-__global__ __launch_bounds__(kF2Block) void edge_kernel_f2(const EdgeArgs a, const int64_t ntiles) {
+__global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const EdgeArgs a, const int64_t ntiles) {
   constexpr int NFB = L / 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int MAT_BYTES = L * L * 4;
@@ -342,7 +364,7 @@ __global__ __launch_bounds__(kF2Block) void edge_kernel_f2(const EdgeArgs a, con
   for (int m = 0; m < a.nl; ++m) {
     const f32x4* src = reinterpret_cast<const f32x4*>(m == 0 ? a.w0e : a.layers[m].w);
     f32x4* dst = reinterpret_cast<f32x4*>(smem + m * MAT_BYTES);
-    for (int i = tid; i < MAT_BYTES / 16; i += kF2Block) dst[i] = src[i];
+    for (int i = tid; i < MAT_BYTES / 16; i += 64 * edge_waves<L>()) dst[i] = src[i];
   }
   __syncthreads();
   unsigned char* win = smem + a.nl * MAT_BYTES + wave * kWinBytes;
@@ -357,8 +379,8 @@ __global__ __launch_bounds__(kF2Block) void edge_kernel_f2(const EdgeArgs a, con
   const int64_t tiles_per_xcd = (ntiles + 7) >> 3;
   const int64_t t_begin = xcd * tiles_per_xcd;
   const int64_t t_end = t_begin + tiles_per_xcd < ntiles ? t_begin + tiles_per_xcd : ntiles;
-  const int64_t stride = bpx * kF2Waves;
-  int64_t tile = t_begin + local * kF2Waves + wave;
+  const int64_t stride = bpx * edge_waves<L>();
+  int64_t tile = t_begin + local * edge_waves<L>() + wave;
 
   // lane c (both halves) holds source / destination of tile row c; the next tile's are loaded ahead
   int s0 = 0, d0 = 0, s1 = 0, d1 = 0;
@@ -377,7 +399,7 @@ __global__ __launch_bounds__(kF2Block) void edge_kernel_f2(const EdgeArgs a, con
   // so their latency runs under that work.  Measured at L = 64: -2.4 % per launch (L = 32: +30 %, off).  At L = 128 the 64 loop-carried
   // registers do not fit beside the accumulators (the kernel spills, and every scratch reload drains the in-order
   // memory counter, prefetch included: +50 %), so the wide kernel keeps the loads at the top of the tile.
-  constexpr bool PIPE = !EMB && L == 64;
+  constexpr bool PIPE = !EMB && L == 64 && edge_waves<L>() == 8;
   ELanding<L> la;  // rows of e of the tile at hand: la.v[pass][it] = e[row it*8 + lane/8][32 pass + 4 (lane % 8) .. +3]
   Tile<L> pn;      // P_s[src] of the tile at hand, accumulator layout (becomes the accumulator)
   auto load_e = [&](int64_t t) {
@@ -630,7 +652,7 @@ __global__ __launch_bounds__(kF2Block) void edge_kernel_f2(const EdgeArgs a, con
 // HEAD: the instantiation of the LAST node launch of a SupervisedMPN forward - no projections follow, the decoder's
 // layers and the readout do (kept apart so that neither variant pays the other's registers).
 template <int L, bool SPLIT, bool HEAD>
-__global__ __launch_bounds__(kF2Block) void node_kernel_f2(const NodeArgs a, const int64_t ntiles, const int resident) {
+__global__ __launch_bounds__(64 * node_waves<L>()) void node_kernel_f2(const NodeArgs a, const int64_t ntiles, const int resident) {
   constexpr int NFB = L / 32;
   constexpr int MAT_BYTES = L * L * 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -650,7 +672,7 @@ __global__ __launch_bounds__(kF2Block) void node_kernel_f2(const NodeArgs a, con
   auto stream_in = [&](const float* src, int slot) {
     int lo16 = lane * 16;  // opaque: hoisted out of the batch loop, the per-matrix source addresses would be spilled
     asm volatile("" : "+v"(lo16));
-    for (int j = wave; j < MAT_BYTES / 1024; j += kF2Waves)
+    for (int j = wave; j < MAT_BYTES / 1024; j += node_waves<L>())
       __builtin_amdgcn_global_load_lds(
           (const __attribute__((address_space(1))) void*)(reinterpret_cast<const unsigned char*>(src) + j * 1024 + static_cast<unsigned>(lo16)),
           (__attribute__((address_space(3))) void*)(smem + slot * MAT_BYTES + j * 1024), 16, 0, 0);
@@ -663,8 +685,8 @@ __global__ __launch_bounds__(kF2Block) void node_kernel_f2(const NodeArgs a, con
   const int64_t tiles_per_xcd = (ntiles + 7) >> 3;
   const int64_t t_begin = xcd * tiles_per_xcd;
   const int64_t t_end = t_begin + tiles_per_xcd < ntiles ? t_begin + tiles_per_xcd : ntiles;
-  const int64_t stride = bpx * kF2Waves;
-  const int64_t first = t_begin + local * kF2Waves;
+  const int64_t stride = bpx * node_waves<L>();
+  const int64_t first = t_begin + local * node_waves<L>();
   const int64_t nbatch = first < t_end ? (t_end - first + stride - 1) / stride : 0;  // the same for every wave of the workgroup
   if (nbatch == 0) return;
 
@@ -1028,7 +1050,8 @@ hipError_t launch_pack_f2(int L, const float* W, int ld, int col0, int scale_col
 }
 
 size_t edge_f2_lds_bytes(int L, int nl) {
-  return static_cast<size_t>(nl) * L * L * 4 + static_cast<size_t>(kF2Waves) * kWinBytes;
+  const int waves = L == 64 ? edge_waves<64>() : (L == 32 ? edge_waves<32>() : kF2Waves);
+  return static_cast<size_t>(nl) * L * L * 4 + static_cast<size_t>(waves) * kWinBytes;
 }
 
 bool edge_f2_supported(int L, int nl, int act, int residual, int layer_norm) {
@@ -1046,7 +1069,7 @@ static hipError_t launch_edge_f2_t(const EdgeArgs& a, int num_cus, hipStream_t s
   if (e != hipSuccess) return e;
   int64_t grid = (num_cus / 8) * 8;  // one persistent workgroup per CU, a multiple of the 8 XCDs
   if (grid < 8) grid = 8;
-  hipLaunchKernelGGL((edge_kernel_f2<L, EMB, SPLIT>), dim3(static_cast<unsigned>(grid)), dim3(kF2Block), lds, s, a, ntiles);
+  hipLaunchKernelGGL((edge_kernel_f2<L, EMB, SPLIT>), dim3(static_cast<unsigned>(grid)), dim3(64 * edge_waves<L>()), lds, s, a, ntiles);
   return hipGetLastError();
 }
 template <int L>
@@ -1080,7 +1103,7 @@ static hipError_t launch_node_f2_t(const NodeArgs& a, int num_cus, hipStream_t s
   if (ntiles == 0 || (!a.do_update && !a.do_proj && !HEAD)) return hipSuccess;
   if (HEAD && (a.do_proj || a.n_dense < 1 || !a.do_readout)) return hipErrorInvalidValue;
   const int P = (a.do_update ? a.nl + 1 : 0) + (a.do_proj ? 2 : 0) + (HEAD ? a.n_dense : 0);
-  const size_t mat = static_cast<size_t>(L) * L * 4, wins = static_cast<size_t>(kF2Waves) * kWinBytes;
+  const size_t mat = static_cast<size_t>(L) * L * 4, wins = static_cast<size_t>(node_waves<L>()) * kWinBytes;
   const int resident = P * mat + wins <= 160 * 1024 ? 1 : 0;
   const size_t lds = (resident ? P : 2) * mat + wins;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(node_kernel_f2<L, SPLIT, HEAD>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1088,7 +1111,7 @@ static hipError_t launch_node_f2_t(const NodeArgs& a, int num_cus, hipStream_t s
   if (e != hipSuccess) return e;
   int64_t grid = (num_cus / 8) * 8;  // one persistent workgroup per CU, a multiple of the 8 XCDs
   if (grid < 8) grid = 8;
-  hipLaunchKernelGGL((node_kernel_f2<L, SPLIT, HEAD>), dim3(static_cast<unsigned>(grid)), dim3(kF2Block), lds, s, a, ntiles, resident);
+  hipLaunchKernelGGL((node_kernel_f2<L, SPLIT, HEAD>), dim3(static_cast<unsigned>(grid)), dim3(64 * node_waves<L>()), lds, s, a, ntiles, resident);
   return hipGetLastError();
 }
 
