@@ -102,7 +102,7 @@ SIGNATURES = {
     "amber_mpn_normalize_rows": (C.c_int, [_P, _I64, _I32, _P, _P, _F64, _F64, _P, _P]),
     "amber_mpn_postprocess": (C.c_int, [_GLUE, _P, _P, _P, _P, _I64, _P, _P]),
     "amber_mpn_postprocess_backward": (C.c_int, [_GLUE, _P, _P, _P, _P, _P, _I64, _P, _P]),
-    "amber_mpn_inverse_transform": (C.c_int, [_I32, _P, _I64, _P, _P]),
+    "amber_mpn_inverse_transform": (C.c_int, [_I32, _P, _P, _I64, _P, _P]),
     "amber_mpn_graph_edge_features": (_I32, [C.POINTER(AmberGraphDesc)]),
     "amber_mpn_build_graph": (C.c_int, [C.POINTER(AmberGraphDesc), _I32, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P, _P, _P, _P, _P]),
     "amber_mpn_predict_workspace_bytes": (_SZ, [_DESC, _I64, _I64]),

@@ -1222,14 +1222,14 @@ int amber_mpn_postprocess_backward(const AmberGlueDesc* glue, const float* pred,
   return AMBER_OK;
 }
 
-int amber_mpn_inverse_transform(int32_t transform, const float* in, int64_t n, float* out, void* stream) {
+int amber_mpn_inverse_transform(int32_t transform, const float* in, const float* baseline, int64_t n, float* out, void* stream) {
   if (transform < AMBER_TRANSFORM_NONE || transform > AMBER_TRANSFORM_EXP)
     return fail(AMBER_ERR_UNSUPPORTED, "Unsupported transform type: id %d", transform);
   if (n < 0) return fail(AMBER_ERR_INVALID_ARGUMENT, "negative size");
   if (n == 0) return AMBER_OK;
   if (!in || !out) return fail(AMBER_ERR_INVALID_ARGUMENT, "in / out is NULL");
   (void)hipGetLastError();
-  HIP_TRY(launch_inverse_transform(transform, in, n, out, static_cast<hipStream_t>(stream)), "inverse_transform");
+  HIP_TRY(launch_inverse_transform(transform, in, baseline, n, out, static_cast<hipStream_t>(stream)), "inverse_transform");
   return AMBER_OK;
 }
 

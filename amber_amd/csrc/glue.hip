@@ -47,12 +47,17 @@ __global__ __launch_bounds__(256) void postprocess_bwd_kernel(const PostArgs p, 
   }
 }
 
-__global__ __launch_bounds__(256) void inverse_transform_kernel(int transform, const float* __restrict__ in, int64_t n,
+__device__ __forceinline__ float inverse_one(int transform, float v) {
+  return transform == AMBER_TRANSFORM_SOFTPLUS ? softplus_inverse(v) : (transform == AMBER_TRANSFORM_EXP ? logf(v) : v);
+}
+__global__ __launch_bounds__(256) void inverse_transform_kernel(int transform, const float* __restrict__ in,
+                                                                const float* __restrict__ baseline, int64_t n,
                                                                 float* __restrict__ out) {
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n;
        i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
-    const float v = in[i];
-    out[i] = transform == AMBER_TRANSFORM_SOFTPLUS ? softplus_inverse(v) : (transform == AMBER_TRANSFORM_EXP ? logf(v) : v);
+    float v = inverse_one(transform, in[i]);
+    if (baseline) v = v - inverse_one(transform, baseline[i]);  // residual prediction: prediction_transform.py:121-124
+    out[i] = v;
   }
 }
 
@@ -70,9 +75,9 @@ hipError_t launch_normalize_rows(const float* in, int64_t rows, int width, const
   hipLaunchKernelGGL(normalize_rows_kernel, dim3(grid_for(total)), dim3(256), 0, s, in, total, width, mean, var, eps, clip, out);
   return hipGetLastError();
 }
-hipError_t launch_inverse_transform(int transform, const float* in, int64_t n, float* out, hipStream_t s) {
+hipError_t launch_inverse_transform(int transform, const float* in, const float* baseline, int64_t n, float* out, hipStream_t s) {
   if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(inverse_transform_kernel, dim3(grid_for(n)), dim3(256), 0, s, transform, in, n, out);
+  hipLaunchKernelGGL(inverse_transform_kernel, dim3(grid_for(n)), dim3(256), 0, s, transform, in, baseline, n, out);
   return hipGetLastError();
 }
 hipError_t launch_postprocess(const PostArgs& p, const float* pred, int64_t n, float* out, hipStream_t s) {

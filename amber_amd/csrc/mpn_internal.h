@@ -240,7 +240,7 @@ hipError_t launch_pack_t(int L, const float* W, int ld, int col0, float* out, hi
 // ---- pre / post glue of _predict, glue.hip ----
 hipError_t launch_normalize_rows(const float* in, int64_t rows, int width, const double* mean, const double* var, double eps,
                                  double clip, float* out, hipStream_t s);
-hipError_t launch_inverse_transform(int transform, const float* in, int64_t n, float* out, hipStream_t s);
+hipError_t launch_inverse_transform(int transform, const float* in, const float* baseline, int64_t n, float* out, hipStream_t s);
 hipError_t launch_postprocess(const PostArgs& p, const float* pred, int64_t n, float* out, hipStream_t s);
 hipError_t launch_postprocess_bwd(const PostArgs& p, const float* pred, const float* grad_out, int64_t n, float* grad_pred,
                                   hipStream_t s);

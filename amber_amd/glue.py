@@ -109,15 +109,21 @@ def denormalize(pred: torch.Tensor, mean: torch.Tensor, var: torch.Tensor, epsil
     return postprocess(pred, transform=None, apply_transform=False, mean=mean, var=var, epsilon=epsilon)
 
 
-def inverse_transform(t: torch.Tensor, transform) -> torch.Tensor:
+def inverse_transform(t: torch.Tensor, transform, baseline: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """transform^-1(t) (- transform^-1(baseline) for residual prediction), one kernel."""
     _require_cuda(t, "labels")
     key = transform.lower() if isinstance(transform, str) else transform
     if key not in _lib.TRANSFORM:
         raise ValueError(f"Unsupported transform type: transform_name={transform!r}")
     src = t.to(torch.float32).contiguous()
+    b = None
+    if baseline is not None:
+        b = baseline.to(device=t.device, dtype=torch.float32).contiguous()
+        if b.numel() != src.numel():
+            raise ValueError(f"amber_amd: {src.numel()} labels but a baseline of {b.numel()}")
     out = torch.empty_like(src)
     with torch.cuda.device(t.device):
-        rc = _lib.load().amber_mpn_inverse_transform(_lib.TRANSFORM[key], src.data_ptr(), src.numel(), out.data_ptr(),
+        rc = _lib.load().amber_mpn_inverse_transform(_lib.TRANSFORM[key], src.data_ptr(), _lib.ptr(b), src.numel(), out.data_ptr(),
                                                      _lib.stream_ptr(t.device))
     _lib.check(rc, "inverse_transform")
     return out

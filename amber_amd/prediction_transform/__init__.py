@@ -37,11 +37,10 @@ class PredictionTransform(abc.ABC):
         """Labels into network space: transform^-1(labels) (- transform^-1(baseline) for residual prediction)."""
         if not (self.inverse_transform_in_loss or not is_train):
             return labels
-        labels = self._inverse_transform(labels)
         if self.predict_residual:
             assert baseline is not None, "Baseline must be provided for residual prediction."
-            labels = labels - self._inverse_transform(baseline)
-        return labels
+            return glue.inverse_transform(labels, self.kind, baseline=baseline)
+        return self._inverse_transform(labels)
 
     def _transform(self, prediction: torch.Tensor) -> torch.Tensor:
         return glue.postprocess(prediction, transform=self.kind)

@@ -273,9 +273,10 @@ int amber_mpn_postprocess_backward(const AmberGlueDesc* glue, const float* pred,
                                    const double* pred_mean, const double* pred_var, const float* grad_out, int64_t n,
                                    float* grad_pred, void* stream);
 
-/* transform^-1 on n values (labels into network space for the loss and the label statistics:
- * PredictionTransform.inverse, prediction_transform.py:90-128): softplus: v + log(-expm1(-v)); exp: log(v); none: v. */
-int amber_mpn_inverse_transform(int32_t transform, const float* in, int64_t n, float* out, void* stream);
+/* Labels into network space for the loss and the label statistics (PredictionTransform.inverse,
+ * prediction_transform.py:90-128): out = transform^-1(in) - (baseline ? transform^-1(baseline) : 0), with
+ * transform^-1 = softplus: v + log(-expm1(-v)); exp: log(v); none: v.  baseline (residual prediction) may be NULL. */
+int amber_mpn_inverse_transform(int32_t transform, const float* in, const float* baseline, int64_t n, float* out, void* stream);
 
 /* _predict in one call (inference): normalise x and edge_attr into the workspace, run amber_mpn_forward with the
  * SupervisedMPN head, and apply the post-processing inside the head kernel's readout epilogue (no pass of its own).
