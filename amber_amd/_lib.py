@@ -64,7 +64,8 @@ class AmberGlueDesc(C.Structure):
 
 
 class AmberGraphDesc(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("dim", "add_self_edges", "distance_vector", "euclidean_distance", "edge_curvature")]
+    _fields_ = [(n, C.c_int32) for n in ("dim", "add_self_edges", "distance_vector", "euclidean_distance", "edge_curvature",
+                                         "reserved")] + [("edge_capacity", C.c_int64), ("edge_offset", C.c_int64)]
 
 
 _P = C.c_void_p
@@ -105,6 +106,7 @@ SIGNATURES = {
     "amber_mpn_inverse_transform": (C.c_int, [_I32, _P, _P, _I64, _P, _P]),
     "amber_mpn_graph_edge_features": (_I32, [C.POINTER(AmberGraphDesc)]),
     "amber_mpn_build_graph": (C.c_int, [C.POINTER(AmberGraphDesc), _I32, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P, _P, _P, _P, _P]),
+    "amber_mpn_build_inter_edges": (C.c_int, [C.POINTER(AmberGraphDesc), _I64, _I64, _I64, _P, _P, _P, _P, _P, _P, _P]),
     "amber_mpn_predict_workspace_bytes": (_SZ, [_DESC, _I64, _I64]),
     "amber_mpn_predict": (C.c_int, [_DESC, _GLUE, _P, _P, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                     _P, _SZ, _P]),

@@ -1311,6 +1311,10 @@ int amber_mpn_build_graph(const AmberGraphDesc* gdesc, int32_t num_graphs, const
   if (num_pairs > 0 && num_nodes == 0) return fail(AMBER_ERR_INVALID_ARGUMENT, "pairs without nodes");
   const int F = amber_mpn_graph_edge_features(gdesc);
   const int64_t E = 2 * num_pairs + (gdesc->add_self_edges ? num_nodes : 0);
+  if (gdesc->edge_capacity < 0 || gdesc->edge_offset < 0 ||
+      (gdesc->edge_capacity > 0 && gdesc->edge_offset + E > gdesc->edge_capacity) || (gdesc->edge_capacity == 0 && gdesc->edge_offset != 0))
+    return fail(AMBER_ERR_INVALID_ARGUMENT, "edge_offset + %lld edges do not fit edge_capacity %lld", static_cast<long long>(E),
+                static_cast<long long>(gdesc->edge_capacity));
   if (num_pairs > 0 && (!nbr_a || !nbr_b)) return fail(AMBER_ERR_INVALID_ARGUMENT, "nbr_a / nbr_b is NULL");
   if (E > 0 && !edge_index) return fail(AMBER_ERR_INVALID_ARGUMENT, "edge_index is NULL");
   if (E > 0 && F > 0 && !edge_attr) return fail(AMBER_ERR_INVALID_ARGUMENT, "edge_attr is NULL");
@@ -1327,7 +1331,8 @@ int amber_mpn_build_graph(const AmberGraphDesc* gdesc, int32_t num_graphs, const
   a.F = F;
   a.N = num_nodes;
   a.M = num_pairs;
-  a.E = E;
+  a.E = gdesc->edge_capacity > 0 ? gdesc->edge_capacity : E;
+  a.eoff = gdesc->edge_offset;
   a.node_ptr = node_ptr;
   a.edge_ptr = edge_ptr;
   a.nbr_a = nbr_a;
@@ -1340,6 +1345,41 @@ int amber_mpn_build_graph(const AmberGraphDesc* gdesc, int32_t num_graphs, const
   a.degree_i = reinterpret_cast<int32_t*>(degree);
   a.status = status;
   HIP_TRY(launch_build_graph(a, static_cast<hipStream_t>(stream)), "build_graph");
+  return AMBER_OK;
+}
+
+int amber_mpn_build_inter_edges(const AmberGraphDesc* gdesc, int64_t num_src, int64_t num_dst, int64_t index_offset,
+                                const int64_t* nearest, const double* pos_src, const double* pos_dst, int64_t* edge_index,
+                                float* edge_attr, int32_t* status, void* stream) {
+  if (!gdesc) return fail(AMBER_ERR_INVALID_ARGUMENT, "gdesc is NULL");
+  if (gdesc->dim != 2 && gdesc->dim != 3) return fail(AMBER_ERR_UNSUPPORTED, "positions must have 2 or 3 columns, given %d", gdesc->dim);
+  if (num_src < 0 || num_dst < 0 || index_offset < 0) return fail(AMBER_ERR_INVALID_ARGUMENT, "negative size");
+  if (!status) return fail(AMBER_ERR_INVALID_ARGUMENT, "status is NULL");
+  if (num_src > 0 && num_dst == 0) return fail(AMBER_ERR_INVALID_ARGUMENT, "no destination nodes");
+  const int F = amber_mpn_graph_edge_features(gdesc);
+  const int64_t E = 2 * num_src;
+  if (gdesc->edge_capacity < 0 || gdesc->edge_offset < 0 ||
+      (gdesc->edge_capacity > 0 && gdesc->edge_offset + E > gdesc->edge_capacity) || (gdesc->edge_capacity == 0 && gdesc->edge_offset != 0))
+    return fail(AMBER_ERR_INVALID_ARGUMENT, "edge_offset + %lld edges do not fit edge_capacity %lld", static_cast<long long>(E),
+                static_cast<long long>(gdesc->edge_capacity));
+  if (num_src > 0 && (!nearest || !edge_index)) return fail(AMBER_ERR_INVALID_ARGUMENT, "nearest / edge_index is NULL");
+  if (num_src > 0 && F > 0 && !edge_attr) return fail(AMBER_ERR_INVALID_ARGUMENT, "edge_attr is NULL");
+  if (num_src > 0 && (gdesc->distance_vector || gdesc->euclidean_distance) && (!pos_src || !pos_dst))
+    return fail(AMBER_ERR_INVALID_ARGUMENT, "positions are NULL");
+  (void)hipGetLastError();
+  GraphArgs a{};
+  a.dim = gdesc->dim;
+  a.distance_vector = gdesc->distance_vector ? 1 : 0;
+  a.euclidean_distance = gdesc->euclidean_distance ? 1 : 0;
+  a.edge_curvature = gdesc->edge_curvature ? 1 : 0;
+  a.F = F;
+  a.E = gdesc->edge_capacity > 0 ? gdesc->edge_capacity : E;
+  a.eoff = gdesc->edge_offset;
+  a.edge_index = edge_index;
+  a.edge_attr = edge_attr;
+  a.status = status;
+  HIP_TRY(launch_inter_edges(a, nearest, pos_src, pos_dst, num_src, num_dst, index_offset, static_cast<hipStream_t>(stream)),
+          "build_inter_edges");
   return AMBER_OK;
 }
 

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void graph_pairs_kernel(const GraphArgs a) {
       vb = vb < 0 ? 0 : (vb >= ng ? ng - 1 : vb);
     }
     const int64_t ga = va + n0, gb = vb + n0;
-    const int64_t fwd = base + (j - e0), rev = fwd + Mg;
+    const int64_t fwd = a.eoff + base + (j - e0), rev = fwd + Mg;
     a.edge_index[fwd] = ga;
     a.edge_index[a.E + fwd] = gb;
     a.edge_index[rev] = gb;
@@ -87,10 +87,44 @@ __global__ __launch_bounds__(256) void graph_nodes_kernel(const GraphArgs a) {
     if (a.batch) a.batch[v] = g;
     if (a.add_self_edges) {
       const int64_t e1 = a.edge_ptr[g + 1], n0 = a.node_ptr[g];
-      const int64_t p = 2 * e1 + n0 + (v - n0);  // behind both directions of this graph's pairs
+      const int64_t p = a.eoff + 2 * e1 + n0 + (v - n0);  // behind both directions of this graph's pairs
       a.edge_index[p] = v;
       a.edge_index[a.E + p] = v;
       if (a.F > 0) write_features(a, a.edge_attr + p * a.F, 0.f, 0.f, 0.f, 0.f, 0.f);
+    }
+  }
+}
+
+// Inter-level edges of AMBER's hierarchical observation graph (get_inter_graph_edges, mesh_to_graph.py:239-301): node k
+// of the source (current) mesh <-> its partner nearest[k] of the destination (initial) mesh, both directions:
+//   edge k          : k -> nearest[k] + offset,   features from  pos_src[k] - pos_dst[nearest[k]]
+//   edge n_src + k  : nearest[k] + offset -> k,   the negated vector, the same distance, curvature 0
+// The reference computes these features in float64 numpy (positions as scikit-fem holds them) and casts to float32 at the
+// end; so does this kernel (separately rounded multiply / add, as numpy's sqrt(add.reduce(x * x))).
+__global__ __launch_bounds__(256) void graph_inter_kernel(const GraphArgs a, const int64_t* __restrict__ nearest,
+                                                          const double* __restrict__ pos_src, const double* __restrict__ pos_dst,
+                                                          int64_t n_src, int64_t n_dst, int64_t index_offset) {
+  for (int64_t k = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; k < n_src;
+       k += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    int64_t q = nearest[k];
+    if (q < 0 || q >= n_dst) {
+      *a.status = 1;
+      q = q < 0 ? 0 : n_dst - 1;
+    }
+    const int64_t fwd = a.eoff + k, rev = fwd + n_src;
+    a.edge_index[fwd] = k;
+    a.edge_index[a.E + fwd] = q + index_offset;
+    a.edge_index[rev] = q + index_offset;
+    a.edge_index[a.E + rev] = k;
+    if (a.F > 0) {
+      const double* ps = pos_src + k * a.dim;
+      const double* pd = pos_dst + q * a.dim;
+      const double dx = ps[0] - pd[0], dy = ps[1] - pd[1], dz = a.dim == 3 ? ps[2] - pd[2] : 0.0;
+      double ss = __dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy));
+      if (a.dim == 3) ss = __dadd_rn(ss, __dmul_rn(dz, dz));
+      const float norm = static_cast<float>(sqrt(ss));
+      write_features(a, a.edge_attr + fwd * a.F, static_cast<float>(dx), static_cast<float>(dy), static_cast<float>(dz), norm, 0.f);
+      write_features(a, a.edge_attr + rev * a.F, static_cast<float>(-dx), static_cast<float>(-dy), static_cast<float>(-dz), norm, 0.f);
     }
   }
 }
@@ -112,6 +146,14 @@ unsigned grid_for(int64_t n) {
 }
 
 }  // namespace
+
+hipError_t launch_inter_edges(const GraphArgs& a, const int64_t* nearest, const double* pos_src, const double* pos_dst, int64_t n_src,
+                              int64_t n_dst, int64_t index_offset, hipStream_t s) {
+  hipError_t e = hipMemsetAsync(a.status, 0, sizeof(int32_t), s);
+  if (e != hipSuccess) return e;
+  if (n_src > 0) hipLaunchKernelGGL(graph_inter_kernel, dim3(grid_for(n_src)), dim3(256), 0, s, a, nearest, pos_src, pos_dst, n_src, n_dst, index_offset);
+  return hipGetLastError();
+}
 
 hipError_t launch_build_graph(const GraphArgs& a, hipStream_t s) {
   hipError_t e = hipMemsetAsync(a.status, 0, sizeof(int32_t), s);

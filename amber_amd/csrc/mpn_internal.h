@@ -248,7 +248,8 @@ hipError_t launch_postprocess_bwd(const PostArgs& p, const float* pred, const fl
 // ---- graph construction, graph.hip ----
 struct GraphArgs {
   int32_t G, dim, add_self_edges, distance_vector, euclidean_distance, edge_curvature, F;
-  int64_t N, M, E;             // nodes, undirected pairs, directed edges written (2 M + N with self edges)
+  int64_t N, M, E;             // nodes, undirected pairs, row stride of edge_index (= edges of the whole output)
+  int64_t eoff;                // column of the output at which this call's edges begin
   const int64_t* node_ptr;     // [G+1]
   const int64_t* edge_ptr;     // [G+1]
   const int64_t* nbr_a;        // [M] local ids
@@ -262,6 +263,8 @@ struct GraphArgs {
   int32_t* status;
 };
 hipError_t launch_build_graph(const GraphArgs& a, hipStream_t s);
+hipError_t launch_inter_edges(const GraphArgs& a, const int64_t* nearest, const double* pos_src, const double* pos_dst, int64_t n_src,
+                              int64_t n_dst, int64_t index_offset, hipStream_t s);
 
 size_t csr_workspace_bytes(int64_t N, int64_t E);
 hipError_t csr_build(const int64_t* edge_index, int64_t E, int64_t N, int32_t* rowptr, int32_t* src_sorted,

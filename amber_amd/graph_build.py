@@ -37,15 +37,10 @@ def _mesh_arrays(mesh, node_type: str, edge_feature_names: Sequence[str]) -> Tup
     return pairs.astype(np.int64), pos.astype(np.float32), curv, n
 
 
-def build_graph_batch(meshes: Sequence, edge_feature_names: Sequence[str], node_type: str = "vertex", add_self_edges: bool = True,
-                      device="cuda", with_degree: bool = False, with_csr: bool = True, validate: bool = True) -> GraphBatch:
-    """Batch of observation graphs for `meshes`, built on `device`: edge_index [2, E] (int64), edge_attr [E, F], batch,
-    ptr, optionally `degree` [N] (float32) and the destination-sorted CSR (`amber_csr`, so the first forward skips the
-    sort).  Node features `x` are the caller's to set."""
+def _build(meshes, edge_feature_names, node_type, add_self_edges, dev, with_degree, extra_edges=0):
+    """Intra-mesh part: uploads the meshes' flat arrays once and fills the first 2 M + N columns of edge_index / rows of
+    edge_attr, which are allocated with `extra_edges` more columns for a caller that appends inter-level edges."""
     lib = _lib.load()
-    dev = torch.device(device)
-    if dev.type != "cuda":
-        raise RuntimeError("amber_amd: graph construction runs on the GPU; there is no CPU path")
     if node_type == "element" and "edge_curvature" in edge_feature_names:
         edge_feature_names = [f for f in edge_feature_names if f != "edge_curvature"]  # element graphs have none (:81-90)
     parts = [_mesh_arrays(m, node_type, edge_feature_names) for m in meshes]
@@ -58,14 +53,16 @@ def build_graph_batch(meshes: Sequence, edge_feature_names: Sequence[str], node_
     np.cumsum([p[3] for p in parts], out=node_ptr[1:])
     np.cumsum([p[0].shape[1] for p in parts], out=edge_ptr[1:])
     n, m = int(node_ptr[-1]), int(edge_ptr[-1])
+    e_intra = 2 * m + (n if add_self_edges else 0)
+    e = e_intra + extra_edges
     gdesc = _lib.AmberGraphDesc(dim=dim, add_self_edges=int(bool(add_self_edges)),
                                 distance_vector=int("distance_vector" in edge_feature_names),
                                 euclidean_distance=int("euclidean_distance" in edge_feature_names),
-                                edge_curvature=int("edge_curvature" in edge_feature_names))
+                                edge_curvature=int("edge_curvature" in edge_feature_names),
+                                edge_capacity=e if extra_edges else 0, edge_offset=0)
     f = lib.amber_mpn_graph_edge_features(C.byref(gdesc))
     if f < 0:
         raise ValueError(f"amber_amd: positions must have 2 or 3 columns, given {dim}")
-    e = 2 * m + (n if add_self_edges else 0)
 
     def up(arrs, dtype, width=None):  # host staging: ONE upload per array for the whole batch
         cat = np.concatenate(arrs, axis=0) if arrs else np.zeros((0,) if width is None else (0, width), dtype=dtype)
@@ -85,13 +82,82 @@ def build_graph_batch(meshes: Sequence, edge_feature_names: Sequence[str], node_
                                        pos.data_ptr(), _lib.ptr(curv), n, m, edge_index.data_ptr(), edge_attr.data_ptr(),
                                        batch.data_ptr(), _lib.ptr(degree), status.data_ptr(), _lib.stream_ptr(dev))
     _lib.check(rc, "build_graph")
-    if validate and int(status.item()) != 0:
+    return dict(gdesc=gdesc, edge_index=edge_index, edge_attr=edge_attr, batch=batch, degree=degree, status=status, node_ptr=nptr,
+                node_counts=[p[3] for p in parts], e_intra=e_intra, n=n)
+
+
+def _device(device) -> torch.device:
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise RuntimeError("amber_amd: graph construction runs on the GPU; there is no CPU path")
+    return dev
+
+
+def build_graph_batch(meshes: Sequence, edge_feature_names: Sequence[str], node_type: str = "vertex", add_self_edges: bool = True,
+                      device="cuda", with_degree: bool = False, with_csr: bool = True, validate: bool = True) -> GraphBatch:
+    """Batch of observation graphs for `meshes`, built on `device`: edge_index [2, E] (int64), edge_attr [E, F], batch,
+    ptr, optionally `degree` [N] (float32) and the destination-sorted CSR (`amber_csr`, so the first forward skips the
+    sort).  Node features `x` are the caller's to set."""
+    dev = _device(device)
+    r = _build(meshes, edge_feature_names, node_type, add_self_edges, dev, with_degree)
+    if validate and int(r["status"].item()) != 0:
         raise IndexError("amber_amd: a mesh edge refers to a node outside its mesh")
-    out = GraphBatch(edge_index=edge_index, edge_attr=edge_attr, batch=batch, ptr=nptr, num_graphs=len(parts))
-    if degree is not None:
-        out.degree = degree
+    out = GraphBatch(edge_index=r["edge_index"], edge_attr=r["edge_attr"], batch=r["batch"], ptr=r["node_ptr"], num_graphs=len(meshes))
+    if r["degree"] is not None:
+        out.degree = r["degree"]
     if with_csr:
-        out.amber_csr = build_csr(edge_index, n, validate=False)
+        out.amber_csr = build_csr(r["edge_index"], r["n"], validate=False)
+    return out
+
+
+def build_hierarchical_graph(mesh, initial_mesh, nearest, edge_feature_names: Sequence[str], node_type: str = "vertex",
+                             add_self_edges: bool = True, device="cuda", x: Optional[torch.Tensor] = None,
+                             initial_x: Optional[torch.Tensor] = None, topology_only: bool = False, with_csr: bool = True,
+                             validate: bool = True) -> GraphBatch:
+    """AMBER's hierarchical observation graph (AmberData._extend_to_hierarchical_graph,
+    /root/reference/src/algorithm/dataloader/amber_data.py:68-115, refinement_depth > 0) on the device:
+
+        edge_index = [ current mesh | initial mesh + n_current | inter-level edges ]   (same order for edge_attr)
+        mask_output = [ True x n_current | False x n_initial ]
+        x           = [ x | 0 ; initial_x (zeros if topology_only) | 1 ]               (when x / initial_x are given)
+
+    `nearest[k]`: the partner of current node k in the initial mesh - `initial_mesh.vertex_tree.query(positions, k=1)[1]`
+    for vertex graphs, `initial_mesh.find_closest_elements(midpoints)` for element graphs (mesh_to_graph.py:254-272):
+    that search stays on the host.  The inter-level features are computed in float64 from the meshes' float64 positions,
+    as the reference's numpy code does."""
+    lib = _lib.load()
+    dev = _device(device)
+    nearest = np.ascontiguousarray(np.asarray(nearest), dtype=np.int64)
+    pos_attr = "vertex_positions" if node_type == "vertex" else "element_midpoints"
+    if node_type not in ("vertex", "element"):
+        raise ValueError(f"Node type {node_type=} not supported")
+    ps = np.ascontiguousarray(np.asarray(getattr(mesh, pos_attr)), dtype=np.float64)
+    pd = np.ascontiguousarray(np.asarray(getattr(initial_mesh, pos_attr)), dtype=np.float64)
+    n_src, n_dst = ps.shape[0], pd.shape[0]
+    if nearest.shape != (n_src,):
+        raise ValueError(f"amber_amd: one partner per current node expected, given {nearest.shape} for {n_src} nodes")
+    r = _build([mesh, initial_mesh], edge_feature_names, node_type, add_self_edges, dev, False, extra_edges=2 * n_src)
+    g = r["gdesc"]
+    g.edge_offset = r["e_intra"]
+    near_d, ps_d, pd_d = torch.from_numpy(nearest).to(dev), torch.from_numpy(ps).to(dev), torch.from_numpy(pd).to(dev)
+    status2 = torch.empty(1, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.amber_mpn_build_inter_edges(C.byref(g), n_src, n_dst, n_src, near_d.data_ptr(), ps_d.data_ptr(), pd_d.data_ptr(),
+                                             r["edge_index"].data_ptr(), r["edge_attr"].data_ptr(), status2.data_ptr(),
+                                             _lib.stream_ptr(dev))
+    _lib.check(rc, "build_inter_edges")
+    if validate and (int(r["status"].item()) != 0 or int(status2.item()) != 0):
+        raise IndexError("amber_amd: a mesh edge or inter-level partner refers to a node outside its mesh")
+    mask = torch.zeros(n_src + n_dst, dtype=torch.bool, device=dev)
+    mask[:n_src] = True
+    out = GraphBatch(edge_index=r["edge_index"], edge_attr=r["edge_attr"], mask_output=mask,
+                     batch=torch.zeros(n_src + n_dst, dtype=torch.int64, device=dev))
+    if x is not None and initial_x is not None:
+        xi = torch.zeros_like(initial_x) if topology_only else initial_x
+        out.x = torch.cat([torch.cat([x.to(dev), torch.zeros(n_src, 1, device=dev, dtype=x.dtype)], dim=1),
+                           torch.cat([xi.to(dev), torch.ones(n_dst, 1, device=dev, dtype=x.dtype)], dim=1)], dim=0)
+    if with_csr:
+        out.amber_csr = build_csr(r["edge_index"], n_src + n_dst, validate=False)
     return out
 
 

@@ -312,12 +312,27 @@ typedef struct AmberGraphDesc {
   int32_t distance_vector;    /* edge feature flags ("distance_vector", "euclidean_distance", "edge_curvature") */
   int32_t euclidean_distance;
   int32_t edge_curvature;
+  int32_t reserved;
+  int64_t edge_capacity;      /* columns of the caller's edge_index / rows of edge_attr when this call fills only a part of
+                                 them (a hierarchical graph is assembled by several calls); 0 = exactly this call's edges */
+  int64_t edge_offset;        /* first column this call writes */
 } AmberGraphDesc;
 int32_t amber_mpn_graph_edge_features(const AmberGraphDesc* gdesc);
 int amber_mpn_build_graph(const AmberGraphDesc* gdesc, int32_t num_graphs, const int64_t* node_ptr, const int64_t* edge_ptr,
                           const int64_t* nbr_a, const int64_t* nbr_b, const float* positions, const float* curvature,
                           int64_t num_nodes, int64_t num_pairs, int64_t* edge_index, float* edge_attr, int64_t* batch,
                           float* degree, int32_t* status, void* stream);
+
+/* Inter-level edges of the hierarchical observation graph (get_inter_graph_edges, src/mesh_util/transforms/
+ * mesh_to_graph.py:239-301; used by AmberData._extend_to_hierarchical_graph, src/algorithm/dataloader/amber_data.py:68-115):
+ * source node k <-> nearest[k] + index_offset, both directions, 2 * num_src edges written at gdesc->edge_offset:
+ *   columns [0, num_src): k -> partner with features of pos_src[k] - pos_dst[nearest[k]]; columns [num_src, 2 num_src): back.
+ * nearest[k] is the partner in the destination mesh (closest vertex / containing element: the host's KD-tree or element
+ * finder); positions are FLOAT64 [n, dim] device arrays and the features are computed in float64 and cast, as the
+ * reference does in numpy: bit-exact.  edge_curvature, if selected, is 0 for these edges. */
+int amber_mpn_build_inter_edges(const AmberGraphDesc* gdesc, int64_t num_src, int64_t num_dst, int64_t index_offset,
+                                const int64_t* nearest, const double* pos_src, const double* pos_dst, int64_t* edge_index,
+                                float* edge_attr, int32_t* status, void* stream);
 
 int amber_mpn_abi_version(void);
 const char* amber_mpn_last_error(void);

@@ -45,6 +45,39 @@ def mesh_edges(pairs: np.ndarray, positions: np.ndarray, num_nodes: int, edge_fe
     return edge_attr, edge_index
 
 
+def inter_graph_edges(src_positions: np.ndarray, dest_positions: np.ndarray, nearest: np.ndarray, edge_feature_names: Sequence[str],
+                      node_type: str = "vertex") -> Tuple[torch.Tensor, torch.Tensor]:
+    """get_inter_graph_edges (mesh_to_graph.py:239-301) after the nearest-partner search (:254-272, host KD-tree /
+    element finder: `nearest` is its result): float64 numpy features, cast to float32 at the end."""
+    index_offset = src_positions.shape[0]
+    src_idx = np.arange(index_offset)
+    dest_pos = dest_positions[nearest]
+    dest_idx = nearest + index_offset
+    positions1 = np.concatenate((src_positions, dest_pos), axis=0)
+    positions2 = np.concatenate((dest_pos, src_positions), axis=0)
+    indices1 = np.concatenate((src_idx, dest_idx), axis=0)
+    indices2 = np.concatenate((dest_idx, src_idx), axis=0)
+    feats = []
+    if "distance_vector" in edge_feature_names:
+        feats.extend(list((positions1 - positions2).T))
+    if "euclidean_distance" in edge_feature_names:
+        feats.append(np.linalg.norm(positions1 - positions2, axis=1))
+    if node_type == "vertex" and "edge_curvature" in edge_feature_names:
+        feats.append(np.zeros(len(positions1)))
+    edge_index = torch.tensor(np.vstack((indices1, indices2))).long()
+    edge_attr = torch.tensor(np.array(feats).T, dtype=torch.float32)
+    return edge_attr, edge_index
+
+
+def hierarchical_graph(graph_ea, graph_ei, n_current, initial_ea, initial_ei, n_initial, inter_ea, inter_ei):
+    """AmberData._extend_to_hierarchical_graph, refinement_depth > 0 (src/algorithm/dataloader/amber_data.py:98-115):
+    (edge_attr, edge_index, mask_output)."""
+    ei = torch.cat([graph_ei, initial_ei + n_current, inter_ei], dim=1)
+    ea = torch.cat([graph_ea, initial_ea, inter_ea], dim=0)
+    mask = torch.cat([torch.ones(n_current), torch.zeros(n_initial)], dim=0).bool()
+    return ea, ei, mask
+
+
 def curvature_per_pair(num_pairs: int, boundary_edges: np.ndarray, boundary_edge_curvatures: np.ndarray) -> np.ndarray:
     """mesh_to_graph.py:127-129: zeros, boundary pairs overwritten."""
     c = np.zeros(num_pairs)

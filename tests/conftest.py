@@ -26,7 +26,12 @@ def glue_cases():
 
 
 def graph_cases():
-    return sorted(f[6:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and f.startswith("graph_"))
+    return sorted(f[6:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and f.startswith("graph_") and not f.startswith("graph_hier_"))
+
+
+def hier_cases():
+    """Fixtures of the hierarchical observation graph (inter-level edges), load with load_graph(name)."""
+    return sorted(f[6:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and f.startswith("graph_hier_"))
 
 
 def load_graph(name):

@@ -37,7 +37,7 @@ for _name, _attr in (("src.tasks.domains.mesh_wrapper", "MeshWrapper"), ("src.ta
     sys.modules[_name] = _m
 
 from src.mesh_util.transforms.mesh_to_graph import (  # noqa: E402  (REFERENCE)
-    get_mesh_element_edges, get_mesh_vertex_edges, get_mesh_vertex_features)
+    get_inter_graph_edges, get_mesh_element_edges, get_mesh_vertex_edges, get_mesh_vertex_features)
 
 from amber_amd import synthetic as syn  # noqa: E402
 
@@ -99,5 +99,48 @@ def main():
         print(name, "ok", counts, arrays["g0_edge_attr"].shape)
 
 
+class _Tree:
+    """pykdtree.kdtree.KDTree stand-in with the one call the reference makes: query(points, k=1) -> (dist, index)."""
+
+    def __init__(self, pts):
+        from scipy.spatial import cKDTree
+
+        self.t = cKDTree(pts)
+
+    def query(self, pts, k=1):
+        return self.t.query(pts, k=k)
+
+
+def hierarchical():
+    """Inter-level edges (get_inter_graph_edges) between a fine and a coarse mesh, vertex and element flavours; the
+    nearest-partner search runs on the host (KD-tree stand-in: scipy's cKDTree for the absent pykdtree; for elements the
+    reference's find_closest_elements needs scikit-fem, so the fixture supplies that method from the same tree)."""
+    rng = np.random.default_rng(11)
+    for name, dim, node_type, names in (("hier_vertex2d", 2, "vertex", ["euclidean_distance", "edge_curvature"]),
+                                        ("hier_vertex3d", 3, "vertex", ["distance_vector", "euclidean_distance", "edge_curvature"]),
+                                        ("hier_element2d", 2, "element", ["distance_vector", "euclidean_distance"])):
+        element = node_type == "element"
+        fp, fpos, fnb, fcv = grid_mesh(17, 13, dim, rng)
+        cp, cpos, cnb, ccv = grid_mesh(5, 4, dim, rng)
+        fine, coarse = Mesh(fp, fpos, fnb, fcv, element=element), Mesh(cp, cpos, cnb, ccv, element=element)
+        tree = _Tree(cpos)
+        if element:
+            coarse.find_closest_elements = lambda pts, _t=tree: _t.query(pts, k=1)[1]
+        else:
+            coarse.vertex_tree = tree
+        inter_ea, inter_ei = get_inter_graph_edges(src_mesh=fine, dest_mesh=coarse, node_type=node_type, edge_feature_names=names)
+        fn = get_mesh_element_edges if element else get_mesh_vertex_edges
+        f_ea, f_ei = fn(fine, edge_feature_names=names, add_self_edges=True)
+        c_ea, c_ei = fn(coarse, edge_feature_names=names, add_self_edges=True)
+        meta = dict(names=names, node_type=node_type, dim=dim, n_fine=int(fpos.shape[0]), n_coarse=int(cpos.shape[0]))
+        np.savez_compressed(os.path.join(HERE, f"graph_{name}.npz"), meta=np.array(json.dumps(meta)), fine_pairs=fp, fine_pos=fpos,
+                            fine_boundary=fnb, fine_curv=fcv, coarse_pairs=cp, coarse_pos=cpos, coarse_boundary=cnb, coarse_curv=ccv,
+                            nearest=tree.query(fpos, k=1)[1].astype(np.int64), inter_edge_attr=inter_ea.numpy(),
+                            inter_edge_index=inter_ei.numpy(), fine_edge_attr=f_ea.numpy(), fine_edge_index=f_ei.numpy(),
+                            coarse_edge_attr=c_ea.numpy(), coarse_edge_index=c_ei.numpy())
+        print(name, "ok", inter_ea.shape, inter_ei.shape)
+
+
 if __name__ == "__main__":
     main()
+    hierarchical()

@@ -11,7 +11,7 @@ import torch
 from amber_amd import csr as csr_mod, graph_build, synthetic as syn
 from amber_amd.architecture.supervised_mpn import SupervisedMPN
 from amber_amd.config import default_architecture
-from conftest import graph_cases, load_graph, rel_err
+from conftest import graph_cases, hier_cases, load_graph, rel_err
 from oracle import graph_oracle as gro
 from oracle import mpn_oracle as orc
 
@@ -111,6 +111,36 @@ def test_large_batch_vs_oracle_and_into_the_model(gpu_device):
         got = model.to(gpu_device)(g).cpu()
     want = orc.supervised_mpn_forward(sd, dict(cfg, in_node_features=4, in_edge_features=2, embedding=None), g.x.cpu(), ea, ei, None)
     assert rel_err(got, want) <= 1e-5
+
+
+@pytest.mark.parametrize("name", hier_cases())
+def test_hierarchical_graph_matches_reference(gpu_device, name):
+    """[current mesh | initial mesh + n | inter-level edges] as AmberData._extend_to_hierarchical_graph assembles it, from
+    the reference's own per-part outputs; inter-level features (float64 arithmetic) bit-exact."""
+    meta, d = load_graph(name)
+    el = meta["node_type"] == "element"
+    fine = Mesh(d["fine_pairs"], d["fine_pos"], d["fine_boundary"], d["fine_curv"], el)
+    coarse = Mesh(d["coarse_pairs"], d["coarse_pos"], d["coarse_boundary"], d["coarse_curv"], el)
+    nf, nc = meta["n_fine"], meta["n_coarse"]
+    x, xi = torch.randn(nf, 3), torch.randn(nc, 3)
+    g = graph_build.build_hierarchical_graph(fine, coarse, d["nearest"], meta["names"], node_type=meta["node_type"], device=gpu_device,
+                                             x=x, initial_x=xi, topology_only=True)
+    ea, ei, mask = gro.hierarchical_graph(torch.from_numpy(d["fine_edge_attr"]), torch.from_numpy(d["fine_edge_index"]), nf,
+                                          torch.from_numpy(d["coarse_edge_attr"]), torch.from_numpy(d["coarse_edge_index"]), nc,
+                                          torch.from_numpy(d["inter_edge_attr"]), torch.from_numpy(d["inter_edge_index"]))
+    assert torch.equal(g.edge_index.cpu(), ei) and torch.equal(g.mask_output.cpu(), mask)
+    n_inter = 2 * nf
+    names = meta["names"] if not el else [n for n in meta["names"] if n != "edge_curvature"]
+    _check_attr(g.edge_attr.cpu()[:-n_inter], ea[:-n_inter], names, meta["dim"])
+    assert torch.equal(g.edge_attr.cpu()[-n_inter:], ea[-n_inter:])  # float64 features, one rounding: bit-exact
+    want_x = torch.cat([torch.cat([x, torch.zeros(nf, 1)], 1), torch.cat([torch.zeros_like(xi), torch.ones(nc, 1)], 1)], 0)
+    assert torch.equal(g.x.cpu(), want_x)
+    ref_csr = csr_mod.build_csr(ei.to(gpu_device), nf + nc)
+    assert torch.equal(g.amber_csr.rowptr, ref_csr.rowptr) and torch.equal(g.amber_csr.perm, ref_csr.perm)
+    with pytest.raises(IndexError, match="outside its mesh"):
+        graph_build.build_hierarchical_graph(fine, coarse, np.full(nf, nc), meta["names"], node_type=meta["node_type"], device=gpu_device)
+    with pytest.raises(ValueError, match="one partner per current node"):
+        graph_build.build_hierarchical_graph(fine, coarse, d["nearest"][:-1], meta["names"], node_type=meta["node_type"], device=gpu_device)
 
 
 def test_edge_cases(gpu_device):

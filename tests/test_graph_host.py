@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from amber_amd import graph_build
-from conftest import graph_cases, load_graph
+from conftest import graph_cases, hier_cases, load_graph
 from oracle import graph_oracle as gro
 
 CASES = graph_cases()
@@ -28,6 +28,14 @@ def test_oracle_matches_reference_golden(name):
         assert np.array_equal(ea.numpy(), d[f"g{g}_edge_attr"])
         if f"g{g}_degree" in d:
             assert np.array_equal(gro.degree(pairs).astype(np.float32)[:, None], d[f"g{g}_degree"])
+
+
+@pytest.mark.parametrize("name", hier_cases())
+def test_inter_level_oracle_matches_reference_golden(name):
+    meta, d = load_graph(name)
+    ea, ei = gro.inter_graph_edges(d["fine_pos"], d["coarse_pos"], d["nearest"], meta["names"], meta["node_type"])
+    assert np.array_equal(ei.numpy(), d["inter_edge_index"]) and np.array_equal(ea.numpy(), d["inter_edge_attr"])
+    assert len(hier_cases()) >= 3
 
 
 def test_collation_offsets():
