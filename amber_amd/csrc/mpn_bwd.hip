@@ -541,6 +541,46 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
     part[static_cast<int64_t>(blockIdx.x) * L * (F + 1) + idx] = s;
   }
 }
+// The same for few raw features (F <= kEmbFastF, every mesh graph of the reference): a thread owns one output feature o
+// and one of 256 / L interleaved row slices and keeps all F + 1 sums in registers, so that d is read ONCE (coalesced
+// over o) instead of once per raw feature; the slices are added in slice order through LDS (deterministic).
+constexpr int kEmbFastF = 7;
+template <int L>
+__global__ __launch_bounds__(256) void embed_bwd_fast_kernel(const float* __restrict__ d, const float* __restrict__ raw,
+                                                             const int32_t* __restrict__ perm, int64_t rows, int64_t chunk, int F,
+                                                             float* __restrict__ part) {
+  constexpr int S = 256 / L;  // row slices
+  __shared__ float red[S][kEmbFastF + 1][L];
+  const int o = threadIdx.x % L, sl = threadIdx.x / L;
+  const int64_t r0 = static_cast<int64_t>(blockIdx.x) * chunk;
+  const int64_t r1 = r0 + chunk < rows ? r0 + chunk : rows;
+  float acc[kEmbFastF + 1];
+#pragma unroll
+  for (int k = 0; k <= kEmbFastF; ++k) acc[k] = 0.f;
+  for (int64_t r = r0 + sl; r < r1; r += S) {
+    const float dv = d[r * L + o];
+    const float* pr = raw + (perm ? static_cast<int64_t>(perm[r]) : r) * F;
+#pragma unroll
+    for (int k = 0; k < kEmbFastF; ++k)
+      if (k < F) acc[k] += dv * pr[k];
+    acc[kEmbFastF] += dv;  // bias column (raw = 1)
+  }
+#pragma unroll
+  for (int k = 0; k <= kEmbFastF; ++k) red[sl][k][o] = acc[k];
+  __syncthreads();
+  if (sl == 0) {
+    float* P = part + static_cast<int64_t>(blockIdx.x) * L * (F + 1);
+#pragma unroll
+    for (int k = 0; k <= kEmbFastF; ++k) {
+      if (k < F || k == kEmbFastF) {
+        float sum = red[0][k][o];
+#pragma unroll
+        for (int q = 1; q < S; ++q) sum += red[q][k][o];
+        P[(k == kEmbFastF ? F : k) * L + o] = sum;
+      }
+    }
+  }
+}
 __global__ void embed_bwd_reduce_kernel(const float* __restrict__ part, int G, int L, int F, float* __restrict__ dW,
                                         float* __restrict__ db) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -729,7 +769,14 @@ hipError_t launch_embed_bwd(int L, const float* d, const float* raw, const int32
   if (rows == 0) return hipSuccess;
   int64_t chunk = 0;
   const int G = embed_bwd_chunks(rows, &chunk);
-  hipLaunchKernelGGL(embed_bwd_kernel, dim3(G), dim3(256), 0, s, d, raw, perm, rows, chunk, L, F, part);
+  if (F <= kEmbFastF && L == 32)
+    hipLaunchKernelGGL(embed_bwd_fast_kernel<32>, dim3(G), dim3(256), 0, s, d, raw, perm, rows, chunk, F, part);
+  else if (F <= kEmbFastF && L == 64)
+    hipLaunchKernelGGL(embed_bwd_fast_kernel<64>, dim3(G), dim3(256), 0, s, d, raw, perm, rows, chunk, F, part);
+  else if (F <= kEmbFastF && L == 128)
+    hipLaunchKernelGGL(embed_bwd_fast_kernel<128>, dim3(G), dim3(256), 0, s, d, raw, perm, rows, chunk, F, part);
+  else
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(G), dim3(256), 0, s, d, raw, perm, rows, chunk, L, F, part);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(embed_bwd_reduce_kernel, dim3(cdiv(L * (F + 1), 256)), dim3(256), 0, s, part, G, L, F, dW, db);
