@@ -513,18 +513,20 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
     for (int l = 1; l < a.nl; ++l) {
       const float* wg = a.layers[l].w;
       pow2_scale(wave_max(tile_absmax<L>(acc)), scale, inv);
+      // accumulate from zero (the first MFMA of a block takes the constant 0 as its C operand: no 64 moves to seed the
+      // accumulators) and add the bias with the multiply that takes the result back out of the scaled domain
       Tile<L> nxt;
+      tile_zero<L>(nxt);
+      if (!DBG(8)) gemm_acc<L, SPLIT>(nxt, acc, scale, win, wo, smem + l * MAT_BYTES, lane);
       {
-        const float bs = scale * wg[L * L + 1];
+        const float post = inv * wg[L * L];
 #pragma unroll
         for (int fb = 0; fb < NFB; ++fb) {
-          const float b = a.layers[l].b[32 * fb + n] * bs;
+          const float b = a.layers[l].b[32 * fb + n];
 #pragma unroll
-          for (int i = 0; i < 16; ++i) nxt.a[fb][i] = b;
+          for (int i = 0; i < 16; ++i) nxt.a[fb][i] = fmaf(nxt.a[fb][i], post, b);
         }
       }
-      if (!DBG(8)) gemm_acc<L, SPLIT>(nxt, acc, scale, win, wo, smem + l * MAT_BYTES, lane);
-      tile_scale<L>(nxt, inv * wg[L * L]);
       tile_act_fast<L>(nxt, a.act);
       acc = nxt;
     }
@@ -767,13 +769,7 @@ __global__ __launch_bounds__(64 * node_waves<L>()) void node_kernel_f2(const Nod
           for (int ps = 0; ps < NFB; ++ps) lx.v[ps][it] = px[ps * 8];
         }
         pow2_scale(wave_max(landing_absmax<L>(lx)), scale, inv);
-        const float bs = scale * a.w0x[L * L + 1];
-#pragma unroll
-        for (int fb = 0; fb < NFB; ++fb) {
-          const float bv = a.b0[32 * fb + nq] * bs;
-#pragma unroll
-          for (int i = 0; i < 16; ++i) acc.a[fb][i] = bv;
-        }
+        tile_zero<L>(acc);  // the first MFMAs take the constant 0 as C; the bias joins the final rescale
         const unsigned char* wl = begin_phase(k++);
         if (!DBG(256)) gemm_rows<L, SPLIT>(acc, lx, scale, win, wo, wl, lane);
       }
@@ -828,7 +824,15 @@ __global__ __launch_bounds__(64 * node_waves<L>()) void node_kernel_f2(const Nod
         tile_scale<L>(acc, sg * inv);
         const unsigned char* wl = begin_phase(k++);
         if (!DBG(256)) gemm_rows<L, SPLIT>(acc, lg, sg, win, wo, wl, lane);
-        tile_scale<L>(acc, ig * a.w0x[L * L]);
+        {
+          const float post = ig * a.w0x[L * L];
+#pragma unroll
+          for (int fb = 0; fb < NFB; ++fb) {
+            const float bv = a.b0[32 * fb + nq];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc.a[fb][i] = fmaf(acc.a[fb][i], post, bv);
+          }
+        }
         tile_act_fast<L>(acc, a.act);
       }
 #pragma unroll 1
@@ -837,15 +841,17 @@ __global__ __launch_bounds__(64 * node_waves<L>()) void node_kernel_f2(const Nod
         const float* wg = a.layers[l].w;
         pow2_scale(wave_max(tile_absmax<L>(acc)), scale, inv);
         Tile<L> nxt;
-        const float bs = scale * wg[L * L + 1];
-#pragma unroll
-        for (int fb = 0; fb < NFB; ++fb) {
-          const float bv = a.layers[l].b[32 * fb + nq] * bs;
-#pragma unroll
-          for (int i = 0; i < 16; ++i) nxt.a[fb][i] = bv;
-        }
+        tile_zero<L>(nxt);
         if (!DBG(256)) gemm_acc<L, SPLIT>(nxt, acc, scale, win, wo, wl, lane);
-        tile_scale<L>(nxt, inv * wg[L * L]);
+        {
+          const float post = inv * wg[L * L];
+#pragma unroll
+          for (int fb = 0; fb < NFB; ++fb) {
+            const float bv = a.layers[l].b[32 * fb + nq];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) nxt.a[fb][i] = fmaf(nxt.a[fb][i], post, bv);
+          }
+        }
         tile_act_fast<L>(nxt, a.act);
         acc = nxt;
       }
@@ -915,15 +921,17 @@ __global__ __launch_bounds__(64 * node_waves<L>()) void node_kernel_f2(const Nod
           }
         }
         Tile<L> acc;
-        const float bs = scale * a.w0d[L * L + 1];
-#pragma unroll
-        for (int fb = 0; fb < NFB; ++fb) {
-          const float bv = a.b0e[32 * fb + nq] * bs;
-#pragma unroll
-          for (int i = 0; i < 16; ++i) acc.a[fb][i] = bv;
-        }
+        tile_zero<L>(acc);
         if (!DBG(256)) gemm_acc<L, SPLIT>(acc, v, scale, win, wo, wl, lane);
-        tile_scale<L>(acc, inv * a.w0d[L * L]);
+        {
+          const float post = inv * a.w0d[L * L];
+#pragma unroll
+          for (int fb = 0; fb < NFB; ++fb) {
+            const float bv = a.b0e[32 * fb + nq];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc.a[fb][i] = fmaf(acc.a[fb][i], post, bv);
+          }
+        }
         store_tile(a.Pd, acc);
       }
     }
@@ -937,15 +945,17 @@ __global__ __launch_bounds__(64 * node_waves<L>()) void node_kernel_f2(const Nod
       float scale, inv;
       pow2_scale(wave_max(tile_absmax<L>(v)), scale, inv);
       Tile<L> nxt;
-      const float bs = scale * wg[L * L + 1];
-#pragma unroll
-      for (int fb = 0; fb < NFB; ++fb) {
-        const float bv = a.dense[l].b[32 * fb + nq] * bs;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) nxt.a[fb][i] = bv;
-      }
+      tile_zero<L>(nxt);
       gemm_acc<L, SPLIT>(nxt, v, scale, win, wo, wl, lane);
-      tile_scale<L>(nxt, inv * wg[L * L]);
+      {
+        const float post = inv * wg[L * L];
+#pragma unroll
+        for (int fb = 0; fb < NFB; ++fb) {
+          const float bv = a.dense[l].b[32 * fb + nq];
+#pragma unroll
+          for (int i = 0; i < 16; ++i) nxt.a[fb][i] = fmaf(nxt.a[fb][i], post, bv);
+        }
+      }
       tile_act_fast<L>(nxt, a.dense_act);
       v = nxt;
     }
