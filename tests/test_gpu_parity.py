@@ -335,3 +335,22 @@ def test_full_size_batch_properties(gpu_device):
         with torch.no_grad():
             got_alone = model(alone)
         assert rel_err(got_alone, out1[n0:n1]) <= 2e-6
+
+
+@pytest.mark.parametrize("latent,steps,graphs", [(64, 4, 40), (32, 4, 40)])
+def test_large_batch_properties_other_widths(gpu_device, latent, steps, graphs):
+    """The narrower kernels run 12 (L = 64) / 16 (L = 32) waves per CU; a 4 M-edge batch gives every wave several tiles
+    in every XCD partition.  Same two properties as the full-size test: bit-equal reruns, and each checked graph equals
+    the oracle on that graph alone."""
+    model, sd, cfg = _supervised(latent, steps, 4, 2, gpu_device)
+    g = syn.grid_batch(num_graphs=graphs, nx=120, ny=120)
+    gd = g.to(gpu_device)
+    with torch.no_grad():
+        out1 = model(gd)
+        out2 = model(gd)
+    assert torch.equal(out1, out2) and torch.isfinite(out1).all()
+    for gi in (0, graphs // 2, graphs - 1):
+        n0, n1 = int(g.ptr[gi]), int(g.ptr[gi + 1])
+        e0, e1 = int(g.edge_ptr[gi]), int(g.edge_ptr[gi + 1])
+        want = orc.supervised_mpn_forward(sd, cfg, g.x[n0:n1], g.edge_attr[e0:e1], g.edge_index[:, e0:e1] - n0, None)
+        assert rel_err(out1[n0:n1].cpu(), want) <= FP32_TOL
