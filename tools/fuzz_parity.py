@@ -79,6 +79,8 @@ def main():
     ap.add_argument("--cases", type=int, default=40)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--precision", default="both", choices=["both", "f16x2", "fp32"])
+    ap.add_argument("--grads", action="store_true", help="training path: parameter gradients against autograd through the "
+                    "oracle (smooth activations only: a relu kink within rounding of zero flips between implementations)")
     ap.add_argument("--keep-going", action="store_true", help="report every failing case instead of stopping at the first")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -88,6 +90,14 @@ def main():
     t0 = time.time()
     for case in range(args.cases):
         cfg = random_cfg(rng)
+        if args.grads:  # what the training path supports (supervised_mpn.py: no decoder normalisation), smooth
+            cfg["stack"]["mlp"]["activation_function"] = "tanh"
+            cfg["decoder"]["activation_function"] = "tanh"
+            cfg["decoder"]["regularization"]["latent_normalization"] = None
+            cfg["edge_dropout"] = 0.0
+            for k in ("residual_connections", "layer_norm"):  # 'outer' is not built for training
+                cfg["stack"][k] = "inner" if cfg["stack"][k] == "outer" else cfg["stack"][k]
+            cfg["embedding"] = None  # MLP input embeddings are not built for training
         fn, fe = int(rng.choice([0, 1, 3, 4, 7, 12])), int(rng.choice([0, 1, 2, 5, 9]))
         g, kind = random_batch(rng, fn, fe)
         torch.manual_seed(int(rng.integers(1 << 30)))
@@ -114,6 +124,42 @@ def main():
         wx64, we64 = orc.mpn_forward(sd64, ocfg, g.x.double(), g.edge_attr.double(), g.edge_index, prefix="mpn.")
         noise = (rel_err(want.double(), want64), rel_err(wx.double(), wx64), rel_err(we.double(), we64) if we.numel() else 0.0)
         bars = [max(TOL, 4 * v) for v in noise]
+        if args.grads:
+            grad_out = torch.randn(want.shape)
+
+            def oracle_grads(params, dt):
+                p = {k: (v.to(dt) if v.is_floating_point() else v).clone().requires_grad_(v.is_floating_point()) for k, v in params.items()}
+                o = orc.supervised_mpn_forward(p, ocfg, g.x.to(dt), g.edge_attr.to(dt), g.edge_index, g.mask_output)
+                (o * grad_out.to(dt)).sum().backward()
+                return {k: v.grad for k, v in p.items() if v.grad is not None}
+
+            g32, g64 = oracle_grads(sd, torch.float32), oracle_grads(sd, torch.float64)
+            gnoise = max(rel_err(g32[k].double(), g64[k]) for k in g32)
+            model = model.to(dev).train()
+            gb = g.to(dev)
+            for prec in precisions:
+                engine.default_precision = prec
+                model._packed = engine.PackedParams()
+                model.zero_grad(set_to_none=True)
+                out = model(gb)
+                (out * grad_out.to(dev)).sum().backward()
+                errs = {k: rel_err(p.grad.cpu(), g32[k]) for k, p in model.named_parameters()}
+                kmax = max(errs, key=errs.get)
+                ferr = rel_err(out.detach().cpu(), want)
+                ok = errs[kmax] <= max(1e-4, 4 * gnoise) and ferr <= bars[0]
+                worst = max(worst, errs[kmax])
+                st = cfg["stack"]
+                print(f"case {case:3d} {prec:5s} L={cfg['latent_dimension']:3d} steps={st['num_steps']}x{st['num_step_repeats']} "
+                      f"nl={st['mlp']['num_layers']} res={st['residual_connections']} ln={st['layer_norm']} "
+                      f"emb={'mlp' if cfg['embedding'] else 'lin'} dec={cfg['decoder']['num_layers']}/{cfg['decoder']['activation_function']} "
+                      f"F=({fn},{fe}) kind={kind} N={g.x.shape[0]} E={g.edge_attr.shape[0]} fwd={ferr:.1e} grad={errs[kmax]:.1e} "
+                      f"({kmax}) noise={gnoise:.1e} {'ok' if ok else 'FAIL'}", flush=True)
+                if not ok:
+                    failed += 1
+                    if not args.keep_going:
+                        print(f"FAILED at case {case} (seed {args.seed})", flush=True)
+                        sys.exit(1)
+            continue
         model = model.to(dev).eval()
         gb = g.to(dev)
         for prec in precisions:
