@@ -51,6 +51,9 @@ def parse():
                          "BASELINE config 3 shaped batch (airfoil: 3 graphs of ~20.7k nodes / 144k edges, latent 64, 20 MP steps) "
                          "unless --graphs/--nx/--ny/--latent/--mp-steps are given")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--eager-baseline", action="store_true",
+                    help="also time the reference's formulation as PyTorch-ROCm eager ops on this GPU (the oracle's op sequence "
+                         "on cuda tensors, full workload) and report it as `eager_gpu_baseline`; a baseline leg like cpu_baseline")
     ap.add_argument("--cpu-graphs", type=int, default=10, help="graphs in the CPU-baseline sample (10 = 1M edges)")
     args = ap.parse_args()
     defaults = dict(graphs=3, nx=144, ny=144, latent=64, mp_steps=20) if args.train else \
@@ -77,6 +80,33 @@ def cpu_baseline(cfg, state_dict, args):
         dt = time.perf_counter() - t0
     return {"value": e / dt, "unit": "edges/s", "cores": threads, "kind": "port",
             "sample": f"{args.cpu_graphs} of the {args.nx}x{args.ny} graphs (E={e}), one forward, {dt:.1f} s, torch CPU fp32"}
+
+
+def eager_gpu_baseline(cfg, state_dict, g, dev):
+    """What the reference's own formulation costs on this GPU: the oracle's op-for-op restatement (cat -> Linear ->
+    activation -> residual -> LayerNorm -> scatter_add mean ...) as PyTorch-ROCm eager kernels on the full workload.
+    A baseline leg beside cpu_baseline (SURVEY.md section 8d asks for it); never the thing shipped."""
+    from oracle import mpn_oracle as orc
+
+    sd = {k: v.to(dev) for k, v in state_dict.items()}
+    ocfg = dict(cfg, in_node_features=4, in_edge_features=2, embedding=None)
+    x, ea, ei, mask = g.x.to(dev), g.edge_attr.to(dev), g.edge_index.to(dev), g.mask_output.to(dev)
+    e = int(ei.shape[1])
+    times = []
+    with torch.no_grad():
+        for _ in range(3):  # first pass = warm-up
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            out = orc.supervised_mpn_forward(sd, ocfg, x, ea, ei, mask)
+            torch.cuda.synchronize(dev)
+            times.append(time.perf_counter() - t0)
+    dt = min(times[1:])
+    peak = torch.cuda.max_memory_allocated(dev) / 2**30
+    del out, sd, x, ea, ei, mask
+    torch.cuda.empty_cache()
+    return {"value": e / dt, "unit": "edges/s", "kind": "port", "ms_per_forward": dt * 1e3,
+            "sample": f"full workload (E={e}), best of 2 after 1 warm-up, torch {torch.__version__} eager fp32 on cuda:0, "
+                      f"peak allocated {peak:.0f} GiB"}
 
 
 def train_bench(args):
@@ -209,7 +239,7 @@ def main():
     total_edges, t = float(edges_done.item()), float(t_max.item())
 
     # ---- per-kernel device time, measured live with HIP events on the launch stream (rank 0) ----
-    roofline = roofline_hbm = kernels = cpu = None
+    roofline = roofline_hbm = kernels = cpu = eager = None
     if rank == 0:
         L, S = args.latent, args.mp_steps
         desc = engine.make_desc(has_head=True, decoder_layers=2, decoder_activation="leakyrelu", decoder_norm=None,
@@ -256,6 +286,8 @@ def main():
                         "note": "executed fp16 MFMA flops = 3 x useful E*4L^2 (hi*hi, hi*lo, lo*hi); not the binding roof"}
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(cfg, state_dict, args)
+        if world == 1 and args.eager_baseline:
+            eager = eager_gpu_baseline(cfg, state_dict, g, dev)
 
     if rank == 0:
         value = total_edges / t
@@ -273,6 +305,8 @@ def main():
             "hbm_roofline_frac_whole_forward": (bytes_fwd / (t / args.steps)) / (HBM_PEAK_GBS * 1e9) if world == 1 else None,
             "roofline": roofline, "roofline_mfma": roofline_hbm, "kernels": kernels, "cpu_baseline": cpu,
         }
+        if eager is not None:
+            line["eager_gpu_baseline"] = eager
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

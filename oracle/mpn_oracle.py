@@ -54,10 +54,10 @@ def _activation(name: str):
 def scatter_mean(src: torch.Tensor, index: torch.Tensor, dim_size: int) -> torch.Tensor:
     """torch_scatter.scatter_mean(src, index, dim=0, dim_size=N) restated (third party, absent).
     Call site: src/mpn/message_passing_modules.py:68.  Zero in-degree rows stay 0."""
-    out = torch.zeros(dim_size, src.shape[1], dtype=src.dtype)
+    out = torch.zeros(dim_size, src.shape[1], dtype=src.dtype, device=src.device)
     out.scatter_add_(0, index.view(-1, 1).expand_as(src), src)
-    count = torch.zeros(dim_size, dtype=src.dtype)
-    count.scatter_add_(0, index, torch.ones(index.shape[0], dtype=src.dtype))
+    count = torch.zeros(dim_size, dtype=src.dtype, device=src.device)
+    count.scatter_add_(0, index, torch.ones(index.shape[0], dtype=src.dtype, device=src.device))
     count.clamp_(min=1)
     return out.true_divide_(count.view(-1, 1))
 

@@ -1,10 +1,10 @@
 """Randomised parity sweep: random network configurations x random graph batches, HIP path (C ABI) against the CPU
-oracle.  Not part of the test suite (tests/ holds the fixed cases): run on the GPU box after kernel changes,
-    python -u tools/fuzz_parity.py --cases 60 --seed 1 [--precision f16x2|fp32]
-Prints one line per case and exits non-zero on the first case above the 1e-5 bar (the bar widens to 4x the
-case's own float32 rounding noise, oracle32 against oracle64, where that is larger: random networks can be
-ill-conditioned).  Checks the readout, the node
-latents and the edge latents (all three outputs of the path), plus bit-equal reruns."""
+oracle.  Not collected by pytest (the test_*.py files hold the fixed cases; it lives in tests/ because it calls the
+oracle).  Run on the GPU box after kernel changes:
+    python -u tests/fuzz_parity.py --cases 60 --seed 1 [--precision f16x2|fp32] [--grads] [--keep-going]
+One line per case; exits non-zero on a case above the 1e-5 bar (1e-4 for gradients).  The bar widens to 4x the case's
+own float32 rounding noise (oracle in float32 against the oracle in float64) where that is larger: random networks
+can be ill-conditioned.  Checks the readout, the node latents and the edge latents, plus bit-equal reruns."""
 import argparse
 import os
 import sys
