@@ -203,7 +203,14 @@ def _sync_flat_gradient(flat_grad: torch.Tensor) -> None:
 
     if grad_sync is None or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return
-    dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)  # RCCL over xGMI on the GPU box (backend "nccl"); one bucket
+    if flat_grad.is_cuda and dist.get_backend() == "gloo":
+        # gloo is a host backend (CPU tests, one-GPU rehearsals of the multi-rank path).  Stage through the host here:
+        # gloo's own staging of device tensors was seen to hang on ROCm when the stream still had kernels queued.
+        host = flat_grad.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM)
+        flat_grad.copy_(host)
+    else:
+        dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)  # RCCL over xGMI on the GPU box (backend "nccl"); one bucket
     if grad_sync == "mean":
         flat_grad.div_(dist.get_world_size())
 

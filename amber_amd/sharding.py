@@ -79,12 +79,16 @@ def sharded_forward(forward_fn: Callable, batch, rank: int, world_size: int, gat
     local = forward_fn(shard_batch(batch, rank, world_size))
     if not gather or world_size == 1:
         return local
-    sizes = [torch.zeros(1, dtype=torch.int64, device=local.device) for _ in range(world_size)]
-    dist.all_gather(sizes, torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device), group=group)
+    # gloo is a host backend (CPU tests, one-GPU rehearsals): stage device tensors through the host ourselves - its own
+    # staging was seen to hang on ROCm while the stream still had kernels queued.  RCCL ("nccl") takes them as they are.
+    dev = local.device
+    comm = torch.device("cpu") if (dev.type == "cuda" and dist.get_backend(group) == "gloo") else dev
+    sizes = [torch.zeros(1, dtype=torch.int64, device=comm) for _ in range(world_size)]
+    dist.all_gather(sizes, torch.tensor([local.shape[0]], dtype=torch.int64, device=comm), group=group)
     sizes = [int(s.item()) for s in sizes]
     pad = max(sizes)
-    buf = torch.zeros(pad, *local.shape[1:], dtype=local.dtype, device=local.device)
-    buf[: local.shape[0]] = local
+    buf = torch.zeros(pad, *local.shape[1:], dtype=local.dtype, device=comm)
+    buf[: local.shape[0]] = local.to(comm)
     outs = [torch.empty_like(buf) for _ in range(world_size)]
     dist.all_gather(outs, buf, group=group)
-    return torch.cat([o[:s] for o, s in zip(outs, sizes)], dim=0)
+    return torch.cat([o[:s] for o, s in zip(outs, sizes)], dim=0).to(dev)

@@ -54,6 +54,9 @@ def parse():
     ap.add_argument("--eager-baseline", action="store_true",
                     help="also time the reference's formulation as PyTorch-ROCm eager ops on this GPU (the oracle's op sequence "
                          "on cuda tensors, full workload) and report it as `eager_gpu_baseline`; a baseline leg like cpu_baseline")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="development only: run the N > 1 code path with every rank on cuda:0 and the gloo backend (a one-GPU "
+                         "box cannot host RCCL ranks); the printed value is NOT a scaling measurement")
     ap.add_argument("--cpu-graphs", type=int, default=10, help="graphs in the CPU-baseline sample (10 = 1M edges)")
     args = ap.parse_args()
     defaults = dict(graphs=3, nx=144, ny=144, latent=64, mp_steps=20) if args.train else \
@@ -109,18 +112,29 @@ def eager_gpu_baseline(cfg, state_dict, g, dev):
                       f"peak allocated {peak:.0f} GiB"}
 
 
-def train_bench(args):
-    """Secondary metric (not BASELINE's headline): training-step throughput, edges/s of forward + backward."""
+def init_ranks(args):
+    """(rank, world, device, dist-or-None): one process per GPU, RCCL (backend "nccl") over xGMI."""
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    dev = torch.device("cuda", local_rank)
+    if world != args.gpus and world == 1 and args.gpus > 1:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    dev = torch.device("cuda", 0 if args.rehearse_on_one_gpu else local_rank)
     torch.cuda.set_device(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=dev)
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+    return rank, world, dev, dist
+
+
+def train_bench(args):
+    """Secondary metric (not BASELINE's headline): training-step throughput, edges/s of forward + backward."""
+    rank, world, dev, dist = init_ranks(args)
     torch.manual_seed(0)
     cfg = default_architecture(latent_dimension=args.latent, num_steps=args.mp_steps)
     model = SupervisedMPN(cfg, syn.GraphBatch(x=torch.zeros(1, 4), edge_attr=torch.zeros(1, 2))).to(dev).train()
@@ -164,8 +178,8 @@ def train_bench(args):
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": t / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "precision": engine.default_precision, "data": "synthetic",
             "config": {"workload": f"training step (forward with tape, backward, Adam) on {args.graphs} triangulated {args.nx}x{args.ny} "
-                                   f"grids per GPU, N={n} E={e}, latent {args.latent}, {args.mp_steps} MP steps, edge_dropout 0 "
-                                   f"(BASELINE config 3 shape by default)",
+                                   f"grids per GPU, N={n} E={e}, latent {args.latent}, {args.mp_steps} MP steps, edge_dropout {cfg['edge_dropout']} "
+                                   f"with a fresh CSR per step for the kept edges (BASELINE config 3 shape by default)",
                        "parallelism": f"graph-wise dp{world}, one gradient all-reduce per step"}}), flush=True)
     if dist is not None:
         dist.destroy_process_group()
@@ -173,23 +187,15 @@ def train_bench(args):
 
 def main():
     args = parse()
+    if os.environ.get("AMBER_BENCH_WATCHDOG"):  # development: dump every thread's stack and exit if the run takes longer
+        import faulthandler
+
+        faulthandler.dump_traceback_later(float(os.environ["AMBER_BENCH_WATCHDOG"]), exit=True)
     if args.precision:
         engine.default_precision = args.precision
     if args.train:
         return train_bench(args)
-    rank = int(os.environ.get("RANK", 0))
-    local_rank = int(os.environ.get("LOCAL_RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-
-        dist.init_process_group("nccl", device_id=dev)
+    rank, world, dev, dist = init_ranks(args)
 
     # ---- network: BASELINE config 5 (latent 128, 10 MP steps, inner residual + inner LN, leakyrelu) ----
     torch.manual_seed(0)
