@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--ny", type=int, default=None)
     ap.add_argument("--latent", type=int, default=None, help="default 128 (--train: 64)")
     ap.add_argument("--mp-steps", type=int, default=None, help="default 10 (--train: 20)")
+    ap.add_argument("--variant", choices=["grid", "hetero", "brick"], default="grid",
+                    help="grid = BASELINE config 5 (the headline); hetero = grid sides ~ U{80..160} per graph; brick = '3D-like' "
+                         "tetrahedralised 19^3 bricks, in-degree ~15 (SURVEY.md section 8d's variants; secondary lines)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--precision", choices=["fp32", "f16x2", "f16"], default=None,
                     help="MLP contraction precision (default f16x2: fp32-grade, 1e-5; f16: reduced, 1e-2; fp32: exact fp32 MFMA)")
@@ -206,7 +209,11 @@ def main():
     model = model.to(dev)
 
     # ---- data: synthetic mesh-graph batch, resident in HBM ----
-    g = syn.grid_batch(num_graphs=args.graphs, nx=args.nx, ny=args.ny, seed=1234 + (rank if args.scaling == "weak" else 0))
+    seed = 1234 + (rank if args.scaling == "weak" else 0)
+    if args.variant == "brick":
+        g = syn.brick_batch(args.graphs, 19, 19, 19, seed=seed)
+    else:
+        g = syn.grid_batch(num_graphs=args.graphs, nx=args.nx, ny=args.ny, seed=seed, hetero=args.variant == "hetero")
     if args.scaling == "strong" and world > 1:
         g = sharding.shard_batch(g, rank, world)
     gd = g.to(dev)
@@ -299,11 +306,14 @@ def main():
         value = total_edges / t
         bytes_fwd = e * (16 * args.latent + 8) * args.mp_steps + n * 8 * args.latent * args.mp_steps \
             + e * (4 * 2 + 4 * args.latent) + n * (4 * 4 + 4 * args.latent) + n * (4 * args.latent + 4)
+        what = {"grid": f"BASELINE config 5: disjoint batch of {args.graphs} triangulated {args.nx}x{args.ny} grids",
+                "hetero": f"config 5 'hetero' variant: {args.graphs} triangulated grids with sides ~ U{{80..160}}",
+                "brick": f"config 5 '3D-like' variant: {args.graphs} tetrahedralised 19x19x19 bricks (in-degree ~15)"}[args.variant]
         line = {
             "metric": "mpn_forward_edges_per_sec", "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": t / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "precision": engine.default_precision, "data": "synthetic",
-            "config": {"workload": f"BASELINE config 5: disjoint batch of {args.graphs} triangulated {args.nx}x{args.ny} grids per "
+            "config": {"workload": f"{what} per "
                                    f"{'GPU' if args.scaling == 'weak' else 'job'}, N={n} E={e} on rank 0, F_n=4 F_e=2, latent {args.latent}, "
                                    f"{args.mp_steps} MP steps, inner residual + inner LayerNorm, leakyrelu, decoder + readout",
                        "global_edges_per_step": total_edges / args.steps, "parallelism": f"graph-wise dp{world}, no collective"},
