@@ -156,17 +156,27 @@ def mpn_forward(params: Dict[str, torch.Tensor], cfg: dict, x: torch.Tensor, edg
     return x, e
 
 
+def linear_weight(params, prefix):
+    """Weight of a decoder Linear.  With regularization.spectral_norm (mlp.py:62-63, torch.nn.utils.spectral_norm) the
+    state_dict holds weight_orig and the power-iteration vectors weight_u / weight_v; in eval mode the layer uses
+    weight_orig / sigma with sigma = u . (weight_orig v), no iteration (torch/nn/utils/spectral_norm.py, compute_weight)."""
+    if f"{prefix}.weight_orig" in params:
+        w = params[f"{prefix}.weight_orig"]
+        sigma = torch.dot(params[f"{prefix}.weight_u"], torch.mv(w, params[f"{prefix}.weight_v"]))
+        return w / sigma
+    return params[f"{prefix}.weight"]
+
+
 def decoder_mlp(params, prefix, t, dec_cfg: dict, latent: int):
     """MLP.forward of the decoder (src/algorithm/architecture/mlp.py:60-95,128-130), eval mode:
-    per layer Linear -> activation [-> LayerNorm | BatchNorm(eval, running stats)] [-> Dropout = identity].
-    Spectral norm is a weight re-parametrisation: the caller passes the effective weight."""
+    per layer Linear -> activation [-> LayerNorm | BatchNorm(eval, running stats)] [-> Dropout = identity]."""
     act = _activation(dec_cfg["activation_function"])
     reg = dec_cfg.get("regularization") or {}
     norm = reg.get("latent_normalization")
     dropout = reg.get("dropout", 0.0)
     idx = 0
     for _ in range(dec_cfg["num_layers"]):
-        t = act(F.linear(t, params[f"{prefix}.mlp_layers.{idx}.weight"], params[f"{prefix}.mlp_layers.{idx}.bias"]))
+        t = act(F.linear(t, linear_weight(params, f"{prefix}.mlp_layers.{idx}"), params[f"{prefix}.mlp_layers.{idx}.bias"]))
         idx += 2
         if norm in ("layer", "layer_norm"):
             t = F.layer_norm(t, (latent,), params[f"{prefix}.mlp_layers.{idx}.weight"], params[f"{prefix}.mlp_layers.{idx}.bias"], 1e-5)

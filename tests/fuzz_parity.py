@@ -42,7 +42,7 @@ def random_cfg(rng):
                      "residual_connections": mode[int(rng.choice(3, p=[0.15, 0.6, 0.25]))],
                      "mlp": {"activation_function": act, "num_layers": int(rng.choice([1, 2, 2, 2, 3]))}},
            "decoder": {"activation_function": str(rng.choice(["leakyrelu", "relu", "tanh", "elu", "silu", "gelu", "mish"])), "num_layers": int(rng.integers(1, 4)),
-                       "regularization": {"dropout": 0, "spectral_norm": False,
+                       "regularization": {"dropout": 0, "spectral_norm": bool(rng.random() < 0.25),
                                           "latent_normalization": [None, None, "layer", "batch"][int(rng.integers(0, 4))]}}}
     return cfg
 
@@ -112,6 +112,12 @@ def main():
                     b.add_(0.2 * torch.randn(b.shape))
                 if "running_var" in name:
                     b.mul_(0.5 + torch.rand(b.shape))
+            # spectral norm starts from random u, v (sigma = u.Wv can be anything): settle them as training would
+            for m in model.decoder_mlp.mlp_layers:
+                for hook in getattr(m, "_forward_pre_hooks", {}).values():
+                    if type(hook).__name__ == "SpectralNorm":
+                        for _ in range(10):
+                            hook.compute_weight(m, do_power_iteration=True)
         sd = {k: v.clone() for k, v in model.state_dict().items()}
         ocfg = dict(cfg, in_node_features=fn, in_edge_features=fe)
         want = orc.supervised_mpn_forward(sd, ocfg, g.x, g.edge_attr, g.edge_index, g.mask_output)
@@ -128,14 +134,17 @@ def main():
             grad_out = torch.randn(want.shape)
 
             def oracle_grads(params, dt):
-                p = {k: (v.to(dt) if v.is_floating_point() else v).clone().requires_grad_(v.is_floating_point()) for k, v in params.items()}
+                p = {k: (v.to(dt) if v.is_floating_point() else v).clone().requires_grad_(
+                    v.is_floating_point() and not k.endswith(("weight_u", "weight_v"))) for k, v in params.items()}
                 o = orc.supervised_mpn_forward(p, ocfg, g.x.to(dt), g.edge_attr.to(dt), g.edge_index, g.mask_output)
                 (o * grad_out.to(dt)).sum().backward()
                 return {k: v.grad for k, v in p.items() if v.grad is not None}
 
             g32, g64 = oracle_grads(sd, torch.float32), oracle_grads(sd, torch.float64)
             gnoise = max(rel_err(g32[k].double(), g64[k]) for k in g32)
-            model = model.to(dev).train()
+            # training mode, except with spectral norm: there a training-mode forward first advances the power iteration
+            # (as the reference's does), which the oracle's snapshot of the state_dict does not follow
+            model = model.to(dev).train(not cfg["decoder"]["regularization"]["spectral_norm"])
             gb = g.to(dev)
             for prec in precisions:
                 engine.default_precision = prec
@@ -151,7 +160,8 @@ def main():
                 st = cfg["stack"]
                 print(f"case {case:3d} {prec:5s} L={cfg['latent_dimension']:3d} steps={st['num_steps']}x{st['num_step_repeats']} "
                       f"nl={st['mlp']['num_layers']} res={st['residual_connections']} ln={st['layer_norm']} "
-                      f"emb={'mlp' if cfg['embedding'] else 'lin'} dec={cfg['decoder']['num_layers']}/{cfg['decoder']['activation_function']} "
+                      f"emb={'mlp' if cfg['embedding'] else 'lin'} dec={cfg['decoder']['num_layers']}/{cfg['decoder']['activation_function']}"
+                      f"{'/sn' if cfg['decoder']['regularization']['spectral_norm'] else ''} "
                       f"F=({fn},{fe}) kind={kind} N={g.x.shape[0]} E={g.edge_attr.shape[0]} fwd={ferr:.1e} grad={errs[kmax]:.1e} "
                       f"({kmax}) noise={gnoise:.1e} {'ok' if ok else 'FAIL'}", flush=True)
                 if not ok:
@@ -177,7 +187,7 @@ def main():
             print(f"case {case:3d} {prec:5s} L={cfg['latent_dimension']:3d} steps={st['num_steps']}x{st['num_step_repeats']} "
                   f"nl={st['mlp']['num_layers']} act={st['mlp']['activation_function']:9s} res={st['residual_connections']} "
                   f"ln={st['layer_norm']} emb={'mlp' if cfg['embedding'] else 'lin'} dec={cfg['decoder']['num_layers']}/"
-                  f"{cfg['decoder']['regularization']['latent_normalization']} F=({fn},{fe}) kind={kind} N={g.x.shape[0]} "
+                  f"{cfg['decoder']['regularization']['latent_normalization']}{'/sn' if cfg['decoder']['regularization']['spectral_norm'] else ''} F=({fn},{fe}) kind={kind} N={g.x.shape[0]} "
                   f"E={g.edge_attr.shape[0]} out={tuple(out.shape)} err=({errs[0]:.1e},{errs[1]:.1e},{errs[2]:.1e}) noise={max(noise):.1e} "
                   f"{'ok' if ok else 'FAIL'}", flush=True)
             if not ok:

@@ -5,7 +5,7 @@ dependencies torch_geometric, torch_scatter and omegaconf are not installed, so 
 stand-ins under tests/golden/_shims are put on sys.path first.  torch_scatter's
 scatter_mean is restated in the stand-in, so that one link stays "parity unpinned".
 
-Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [case ...]
 Writes tests/golden/<case>.npz holding: the case config (JSON), the reference state_dict, the input graph
 and the reference outputs (node latents, edge latents, SupervisedMPN sizing output).  For the configurations the
 backward kernels take (TRAINABLE), additionally the reference's autograd gradients of sum(out * grad_out) with respect
@@ -53,14 +53,14 @@ def mlp_cfg(act="leakyrelu", layers=2):
 
 
 def arch(latent, steps, residual="inner", layer_norm="inner", act="leakyrelu", layers=2, repeats=1, embedding=None,
-         dec_act="leakyrelu", dec_layers=2, dec_norm=None):
+         dec_act="leakyrelu", dec_layers=2, dec_norm=None, dec_spectral=False):
     return {
         "name": "mpn", "latent_dimension": latent, "create_graph_copy": True, "assert_graph_shapes": True,
         "edge_dropout": 0.1, "embedding": embedding,
         "stack": {"layer_norm": layer_norm, "num_steps": steps, "num_step_repeats": repeats,
                   "residual_connections": residual, "mlp": mlp_cfg(act, layers)},
         "decoder": {"activation_function": dec_act, "num_layers": dec_layers,
-                    "regularization": {"dropout": 0, "spectral_norm": False, "latent_normalization": dec_norm}},
+                    "regularization": {"dropout": 0, "spectral_norm": dec_spectral, "latent_normalization": dec_norm}},
     }
 
 
@@ -99,15 +99,20 @@ CASES = {
     "onelayer_L64": (dict(latent=64, steps=2, layers=1, dec_layers=1, dec_act="gelu"), "hier", 4, 2, 21),
     "embmlp_L32": (dict(latent=32, steps=1, embedding={"mlp": mlp_cfg("leakyrelu", 2)}), "grids", 4, 2, 22),
     "decnorm_L32": (dict(latent=32, steps=1, dec_norm="layer", dec_act="silu"), "random", 4, 2, 23),
+    "specnorm_L32": (dict(latent=32, steps=1, dec_spectral=True), "hier", 4, 2, 24),  # decoder spectral_norm (mlp.py:62-63)
 }
 
 
 # cases inside what amber_mpn_backward is built for (include/amber_mpn.h)
-TRAINABLE = ("debug_L64_s2", "synth_L128_s2", "hier_L64_s3", "none_tanh_L32", "const_edge_L32", "const_node_L32", "repeat_L32_l3")
+TRAINABLE = ("debug_L64_s2", "synth_L128_s2", "hier_L64_s3", "none_tanh_L32", "const_edge_L32", "const_node_L32", "repeat_L32_l3",
+             "specnorm_L32")
 
 
 def main():
+    only = sys.argv[1:]  # optional: regenerate just the named cases
     for name, (akw, kind, fn, fe, seed) in CASES.items():
+        if only and name not in only:
+            continue
         cfg = arch(**akw)
         g = graphs(kind, fn, fe, seed)
         torch.manual_seed(seed)
@@ -117,6 +122,12 @@ def main():
             for pname, p in model.named_parameters():
                 if "layer_norm" in pname:
                     p.add_(0.1 * torch.randn(p.shape))
+        if akw.get("dec_spectral"):
+            # move the power-iteration vectors off their random start: training-mode forwards of the REFERENCE decoder
+            model.train()
+            with torch.no_grad():
+                for _ in range(3):
+                    model.decoder_mlp(torch.randn(7, cfg["latent_dimension"]))
         model.eval()
         batch = Batch(x=g.x.clone(), edge_attr=g.edge_attr.clone(), edge_index=g.edge_index.clone(),
                       batch=g.batch.clone(), mask_output=g.mask_output.clone())

@@ -80,10 +80,11 @@ def test_gradients_match_reference_golden(gpu_device, name):
 
 
 def _oracle_grads(cfg, params, x, edge_attr, edge_index, mask, grad_out):
-    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    # spectral norm's power-iteration vectors are buffers, not parameters
+    p = {k: v.clone().requires_grad_(not k.endswith(("weight_u", "weight_v"))) for k, v in params.items()}
     out = orc.supervised_mpn_forward(p, cfg, x, edge_attr, edge_index, mask)
     (out * grad_out).sum().backward()
-    return out.detach(), {k: v.grad for k, v in p.items()}
+    return out.detach(), {k: v.grad for k, v in p.items() if v.requires_grad}
 
 
 def _cfg(latent, steps, layers=2, act="leakyrelu", residual="inner", layer_norm="inner", repeats=1, dec_layers=2, fn=4, fe=2,

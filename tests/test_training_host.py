@@ -20,10 +20,11 @@ ORACLE_GRAD_TOL = 1e-5
 
 
 def _oracle_grads(cfg, params, x, edge_attr, edge_index, mask, grad_out):
-    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    # spectral norm's power-iteration vectors are buffers, not parameters
+    p = {k: v.clone().requires_grad_(not k.endswith(("weight_u", "weight_v"))) for k, v in params.items()}
     out = orc.supervised_mpn_forward(p, cfg, x, edge_attr, edge_index, mask)
     (out * grad_out).sum().backward()
-    return {k: v.grad for k, v in p.items()}
+    return {k: v.grad for k, v in p.items() if v.requires_grad}
 
 
 @pytest.mark.parametrize("name", TRAINABLE)
