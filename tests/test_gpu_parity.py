@@ -337,6 +337,30 @@ def test_full_size_batch_properties(gpu_device):
         assert rel_err(got_alone, out1[n0:n1]) <= 2e-6
 
 
+def test_batch_beyond_2_31_latent_elements(gpu_device):
+    """E * L = 2.94e9 > 2^31 (230 x 120x120 grids, E = 22.96 M, L = 128; the edge latents alone are 11.8 GB of the 288):
+    every row offset must be 64-bit.  The graphs at the far end of the batch are the ones an int32 offset would corrupt."""
+    model, sd, cfg = _supervised(128, 2, 4, 2, gpu_device)
+    graphs = 230
+    g = syn.grid_batch(num_graphs=graphs, nx=120, ny=120)
+    assert g.edge_index.shape[1] * 128 > 2**31
+    gd = g.to(gpu_device)
+    with torch.no_grad():
+        out = model(gd)
+        _, edges, _ = model.mpn(gd)
+    assert torch.isfinite(out).all()
+    for gi in (0, 215, graphs - 1):
+        n0, n1 = int(g.ptr[gi]), int(g.ptr[gi + 1])
+        e0, e1 = int(g.edge_ptr[gi]), int(g.edge_ptr[gi + 1])
+        ei = g.edge_index[:, e0:e1] - n0
+        want = orc.supervised_mpn_forward(sd, cfg, g.x[n0:n1], g.edge_attr[e0:e1], ei, None)
+        assert rel_err(out[n0:n1].cpu(), want) <= FP32_TOL
+        _, we = orc.mpn_forward(sd, cfg, g.x[n0:n1], g.edge_attr[e0:e1], ei, prefix="mpn.")
+        assert rel_err(edges["edges"]["edge_attr"][e0:e1].cpu(), we) <= FP32_TOL  # returned in edge_index order
+    del edges
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("latent,steps,graphs", [(64, 4, 40), (32, 4, 40)])
 def test_large_batch_properties_other_widths(gpu_device, latent, steps, graphs):
     """The narrower kernels run 12 (L = 64) / 16 (L = 32) waves per CU; a 4 M-edge batch gives every wave several tiles

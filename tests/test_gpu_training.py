@@ -130,6 +130,32 @@ def test_gradients_match_oracle_autograd(gpu_device, latent, steps, layers, kind
     _check_grads(model, want, GRAD_TOL if act == "tanh" else KINK_TOL)
 
 
+def test_backward_beyond_2_31_latent_elements(gpu_device):
+    """E * L = 2.94e9 > 2^31 (230 x 120x120 grids, L = 128, one step): the tape, the backward's row-sized intermediates and
+    every offset into them must be 64-bit.  With a loss that only looks at the LAST graph of the batch, the parameter
+    gradients equal those of that graph run alone (graphs exchange nothing) - and an int32 offset would corrupt exactly
+    that far end."""
+    graphs = 230
+    cfg = _cfg(128, 1, act="tanh")
+    params = orc.init_params(cfg, seed=4)
+    g = syn.grid_batch(num_graphs=graphs, nx=120, ny=120)
+    assert g.edge_index.shape[1] * 128 > 2**31
+    n0, e0 = int(g.ptr[graphs - 1]), int(g.edge_ptr[graphs - 1])
+    d = dict(x=g.x, edge_attr=g.edge_attr, edge_index=g.edge_index, batch=g.batch, mask_output=g.mask_output)
+    model = _model(cfg, params, d, gpu_device).train()
+    grad_tail = torch.randn(g.x.shape[0] - n0, 1, generator=torch.Generator().manual_seed(3)).to(gpu_device)
+    out = model(_batch(d, gpu_device))
+    (out[n0:] * grad_tail).sum().backward()
+    big = {k: p.grad.clone() for k, p in model.named_parameters()}
+    del out
+    model.zero_grad(set_to_none=True)
+    torch.cuda.empty_cache()
+    alone = syn.GraphBatch(x=g.x[n0:], edge_attr=g.edge_attr[e0:], edge_index=g.edge_index[:, e0:] - n0).to(gpu_device)
+    (model(alone) * grad_tail).sum().backward()
+    for k, p in model.named_parameters():
+        assert rel_err(big[k], p.grad) <= GRAD_TOL, k
+
+
 def test_backward_is_deterministic_and_accumulates(gpu_device):
     """Two backward passes give bit-equal gradients (ordered reductions, no float atomics); autograd accumulates them."""
     name = "hier_L64_s3"
