@@ -201,43 +201,50 @@ DEVINL void kstep(Tile<L>& acc, const half8 ah, const half8 al, const unsigned c
   }
 }
 
-// lane-constant byte offsets into the wave's LDS window
+// lane-constant byte offsets into the wave's LDS window.  Four registers; the other ten offsets the two images need
+// differ from these by XOR constants and multiples of 1024 (the swizzles are XORs and the row strides powers of two).
+// The node kernel, which is out of registers, forms them at the point of use (PIN: node launch -3 %, it reloaded ten
+// hoisted offsets from scratch in every tile); the edge kernel has room and lets the compiler hoist them (PIN there:
+// +0.6 %).
 struct WinOff {
-  int ew[4];     // row-piece image ([row][32 features] fp16, 64-byte rows, 16-byte slots XOR-swizzled by (row >> 2) & 3):
-                 // writer, row it*8 + lane/8, 8-byte piece lane % 8
-  int er[2];     // ... reader (A operand of k-step sp): row n, slot 2 sp + h
-  int hw[4];     // transposed image ([feature][32 rows] fp16, 64-byte rows, 8-byte units XOR-swizzled by (row >> 1) & 7):
-                 // writer, image row n, unit 2 g + h
-  int hr[2][2];  // ... transposing reader: k-step sp, chunk t; this lane supplies image row 16 sp + 8 h + 4 t + q, unit 4 colblk + p
+  int ew0;  // row-piece image ([row][32 features] fp16, 64-byte rows, 16-byte slots XOR-swizzled by (row >> 2) & 3):
+            // writer, row it*8 + lane/8, 8-byte piece lane % 8; this is it = 0
+  int er0;  // ... reader (A operand of k-step sp): row n, slot 2 sp + h; this is sp = 0
+  int hw0;  // transposed image ([feature][32 rows] fp16, 64-byte rows, 8-byte units XOR-swizzled by (row >> 1) & 7):
+            // writer, image row n, unit 2 g + h; this is g = 0
+  int hr0;  // ... transposing reader: k-step sp, chunk t; this lane supplies image row 16 sp + 8 h + 4 t + q,
+            // unit 4 colblk + p; this is sp = 0, t = 0
+  // it -> it + 1: row + 8 = 512 bytes further and the swizzle's bit 1 flips (slot ^ 2 = 32 bytes); it -> it + 2: + 1024
+  DEVINL int ew(int it) const { return (ew0 ^ ((it & 1) ? 544 : 0)) + 1024 * (it >> 1); }
+  DEVINL int er(int sp) const { return er0 ^ (sp << 5); }  // slot ^ 2
+  DEVINL int hw(int g) const { return hw0 ^ (g << 4); }    // unit ^ 2 g
+  // t -> 1: row + 4 = 256 bytes further and the swizzle's bit 1 flips (unit ^ 2 = 16 bytes); sp -> 1: row + 16 = + 1024
+  DEVINL int hr(int sp, int t) const { return (hr0 ^ (t ? 272 : 0)) + 1024 * sp; }
+  // keeps the derived offsets from being computed once and for all before the tile loop
+  DEVINL void pin() { asm volatile("" : "+v"(ew0), "+v"(er0), "+v"(hw0), "+v"(hr0)); }
 };
 DEVINL WinOff make_win_off(int lane) {
   WinOff o;
   const int n = lane & 31, h = lane >> 5;
-#pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int rr = it * 8 + (lane >> 3), q = lane & 7;
-    o.ew[it] = rr * 64 + ((((q >> 1) ^ ((rr >> 2) & 3))) << 4) + ((q & 1) << 3);
+  {
+    const int rr = lane >> 3, q = lane & 7;
+    o.ew0 = rr * 64 + ((((q >> 1) ^ ((rr >> 2) & 3))) << 4) + ((q & 1) << 3);
   }
-#pragma unroll
-  for (int sp = 0; sp < 2; ++sp) o.er[sp] = n * 64 + ((((2 * sp + h) ^ ((n >> 2) & 3))) << 4);
-#pragma unroll
-  for (int g = 0; g < 4; ++g) o.hw[g] = n * 64 + ((((2 * g + h) ^ ((n >> 1) & 7))) << 3);
+  o.er0 = n * 64 + (((h ^ ((n >> 2) & 3))) << 4);
+  o.hw0 = n * 64 + (((h ^ ((n >> 1) & 7))) << 3);
   const int gl = lane & 15, q = gl >> 2, p = gl & 3, colblk = (lane >> 4) & 1;
-#pragma unroll
-  for (int sp = 0; sp < 2; ++sp)
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int row = 16 * sp + 8 * h + 4 * t + q;
-      o.hr[sp][t] = row * 64 + ((((4 * colblk + p) ^ ((row >> 1) & 7))) << 3);
-    }
+  const int row = 8 * h + q;
+  o.hr0 = row * 64 + ((((4 * colblk + p) ^ ((row >> 1) & 7))) << 3);
   return o;
 }
 
 // acc += (tile * scale) x W^T for a tile held as whole row pieces (ELanding): 32 features a pass are split into hi/lo
 // fp16, written to the window as a [row][feature] image and read back as the A operand with ds_read_b128
-template <int L, bool SPLIT>
-DEVINL void gemm_rows(Tile<L>& acc, const ELanding<L>& la, float scale, unsigned char* win, const WinOff& o,
+template <int L, bool SPLIT, bool PIN = false>
+DEVINL void gemm_rows(Tile<L>& acc, const ELanding<L>& la, float scale, unsigned char* win, const WinOff& o_in,
                       const unsigned char* wl, int lane) {
+  WinOff o = o_in;
+  if constexpr (PIN) o.pin();
 #pragma unroll
   for (int ps = 0; ps < L / 32; ++ps) {
     wave_sync();  // the previous readers of the window are done
@@ -246,18 +253,18 @@ DEVINL void gemm_rows(Tile<L>& acc, const ELanding<L>& la, float scale, unsigned
       half4 hi, lo;
       if constexpr (SPLIT) {
         split4(la.v[ps][it], scale, hi, lo);
-        *reinterpret_cast<half4*>(win + kLoPlane + o.ew[it]) = lo;
+        *reinterpret_cast<half4*>(win + kLoPlane + o.ew(it)) = lo;
       } else {
         round4(la.v[ps][it], scale, hi);
       }
-      *reinterpret_cast<half4*>(win + o.ew[it]) = hi;
+      *reinterpret_cast<half4*>(win + o.ew(it)) = hi;
     }
     wave_sync();
 #pragma unroll
     for (int sp = 0; sp < 2; ++sp) {
-      const half8 ah = *reinterpret_cast<const half8*>(win + o.er[sp]);
+      const half8 ah = *reinterpret_cast<const half8*>(win + o.er(sp));
       half8 al = ah;
-      if constexpr (SPLIT) al = *reinterpret_cast<const half8*>(win + kLoPlane + o.er[sp]);
+      if constexpr (SPLIT) al = *reinterpret_cast<const half8*>(win + kLoPlane + o.er(sp));
       kstep<L, SPLIT>(acc, ah, al, wl, 2 * ps + sp, lane);
     }
   }
@@ -265,9 +272,11 @@ DEVINL void gemm_rows(Tile<L>& acc, const ELanding<L>& la, float scale, unsigned
 
 // acc += (tile * scale) x W^T for a tile in accumulator layout (feature per lane): 32 features a pass go through the
 // window as a [feature][row] image and come back as the A operand through the transposing read
-template <int L, bool SPLIT>
-DEVINL void gemm_acc(Tile<L>& acc, const Tile<L>& in, float scale, unsigned char* win, const WinOff& o,
+template <int L, bool SPLIT, bool PIN = false>
+DEVINL void gemm_acc(Tile<L>& acc, const Tile<L>& in, float scale, unsigned char* win, const WinOff& o_in,
                      const unsigned char* wl, int lane) {
+  WinOff o = o_in;
+  if constexpr (PIN) o.pin();
 #pragma unroll
   for (int fb = 0; fb < L / 32; ++fb) {
     wave_sync();
@@ -281,16 +290,16 @@ DEVINL void gemm_acc(Tile<L>& acc, const Tile<L>& in, float scale, unsigned char
       half4 hi, lo;
       if constexpr (SPLIT) {
         split4(x, scale, hi, lo);
-        *reinterpret_cast<half4*>(win + kLoPlane + o.hw[g]) = lo;
+        *reinterpret_cast<half4*>(win + kLoPlane + o.hw(g)) = lo;
       } else {
         round4(x, scale, hi);
       }
-      *reinterpret_cast<half4*>(win + o.hw[g]) = hi;
+      *reinterpret_cast<half4*>(win + o.hw(g)) = hi;
     }
     wave_sync();
 #pragma unroll
     for (int sp = 0; sp < 2; ++sp) {
-      const half4 a0 = lds_read_tr(win + o.hr[sp][0]), a1 = lds_read_tr(win + o.hr[sp][1]);
+      const half4 a0 = lds_read_tr(win + o.hr(sp, 0)), a1 = lds_read_tr(win + o.hr(sp, 1));
       half8 ah, al;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
@@ -299,7 +308,7 @@ DEVINL void gemm_acc(Tile<L>& acc, const Tile<L>& in, float scale, unsigned char
       }
       al = ah;
       if constexpr (SPLIT) {
-        const half4 b0 = lds_read_tr(win + kLoPlane + o.hr[sp][0]), b1 = lds_read_tr(win + kLoPlane + o.hr[sp][1]);
+        const half4 b0 = lds_read_tr(win + kLoPlane + o.hr(sp, 0)), b1 = lds_read_tr(win + kLoPlane + o.hr(sp, 1));
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           al[t] = b0[t];
@@ -771,7 +780,7 @@ __global__ __launch_bounds__(64 * node_waves<L>()) void node_kernel_f2(const Nod
         pow2_scale(wave_max(landing_absmax<L>(lx)), scale, inv);
         tile_zero<L>(acc);  // the first MFMAs take the constant 0 as C; the bias joins the final rescale
         const unsigned char* wl = begin_phase(k++);
-        if (!DBG(256)) gemm_rows<L, SPLIT>(acc, lx, scale, win, wo, wl, lane);
+        if (!DBG(256)) gemm_rows<L, SPLIT, true>(acc, lx, scale, win, wo, wl, lane);
       }
       {
         // ---- whole row pieces of the aggregate: sums of the edge kernel -> mean ----
@@ -823,7 +832,7 @@ __global__ __launch_bounds__(64 * node_waves<L>()) void node_kernel_f2(const Nod
         pow2_scale(wave_max(landing_absmax<L>(lg)), sg, ig);
         tile_scale<L>(acc, sg * inv);
         const unsigned char* wl = begin_phase(k++);
-        if (!DBG(256)) gemm_rows<L, SPLIT>(acc, lg, sg, win, wo, wl, lane);
+        if (!DBG(256)) gemm_rows<L, SPLIT, true>(acc, lg, sg, win, wo, wl, lane);
         {
           const float post = ig * a.w0x[L * L];
 #pragma unroll
@@ -842,7 +851,7 @@ __global__ __launch_bounds__(64 * node_waves<L>()) void node_kernel_f2(const Nod
         pow2_scale(wave_max(tile_absmax<L>(acc)), scale, inv);
         Tile<L> nxt;
         tile_zero<L>(nxt);
-        if (!DBG(256)) gemm_acc<L, SPLIT>(nxt, acc, scale, win, wo, wl, lane);
+        if (!DBG(256)) gemm_acc<L, SPLIT, true>(nxt, acc, scale, win, wo, wl, lane);
         {
           const float post = inv * wg[L * L];
 #pragma unroll
@@ -903,7 +912,7 @@ __global__ __launch_bounds__(64 * node_waves<L>()) void node_kernel_f2(const Nod
         const unsigned char* wl = begin_phase(k++);
         Tile<L> acc;
         tile_zero<L>(acc);
-        if (!DBG(256)) gemm_acc<L, SPLIT>(acc, v, scale, win, wo, wl, lane);
+        if (!DBG(256)) gemm_acc<L, SPLIT, true>(acc, v, scale, win, wo, wl, lane);
         tile_scale<L>(acc, inv * a.w0s[L * L]);
         store_tile(a.Ps, acc);
       }
@@ -922,7 +931,7 @@ __global__ __launch_bounds__(64 * node_waves<L>()) void node_kernel_f2(const Nod
         }
         Tile<L> acc;
         tile_zero<L>(acc);
-        if (!DBG(256)) gemm_acc<L, SPLIT>(acc, v, scale, win, wo, wl, lane);
+        if (!DBG(256)) gemm_acc<L, SPLIT, true>(acc, v, scale, win, wo, wl, lane);
         {
           const float post = inv * a.w0d[L * L];
 #pragma unroll
@@ -946,7 +955,7 @@ __global__ __launch_bounds__(64 * node_waves<L>()) void node_kernel_f2(const Nod
       pow2_scale(wave_max(tile_absmax<L>(v)), scale, inv);
       Tile<L> nxt;
       tile_zero<L>(nxt);
-      gemm_acc<L, SPLIT>(nxt, v, scale, win, wo, wl, lane);
+      gemm_acc<L, SPLIT, true>(nxt, v, scale, win, wo, wl, lane);
       {
         const float post = inv * wg[L * L];
 #pragma unroll
