@@ -749,6 +749,13 @@ __global__ __launch_bounds__(64 * node_waves<L>()) void node_kernel_f2(const Nod
     // hoisted out of the loop they are spilled, and every scratch reload drains the in-order memory counter)
     int hq = 4 * h * L + n, nq = n, lq = lane, h4 = 4 * h;
     asm volatile("" : "+v"(hq), "+v"(nq), "+v"(lq), "+v"(h4));
+    // the sixteen row numbers are formed again in every phase that uses them (one add each, partial tiles only): shared
+    // between the phases they stay live across the contractions and are spilled inside the tile loop
+#ifndef AMBER_NODE_NO_REPIN
+#define AMBER_REPIN_H4 asm volatile("" : "+v"(h4), "+v"(hq))
+#else
+#define AMBER_REPIN_H4
+#endif
     Tile<L> v;  // the tile's node features in accumulator layout (after the update: x')
     int k = 0;
     if (a.do_update) {
@@ -866,6 +873,7 @@ __global__ __launch_bounds__(64 * node_waves<L>()) void node_kernel_f2(const Nod
       }
       // order of message_passing_block.py:124-125: inner residual, inner LayerNorm
       if (a.residual == AMBER_MODE_INNER) {
+        AMBER_REPIN_H4;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const unsigned off = nvalid == kTile ? static_cast<unsigned>(hq + (8 * (i >> 2) + (i & 3)) * L)
@@ -887,6 +895,7 @@ __global__ __launch_bounds__(64 * node_waves<L>()) void node_kernel_f2(const Nod
     // store a tile in accumulator layout as rows n0 .. n0 + nvalid - 1 of `out`
     auto store_tile = [&](float* out, const Tile<L>& t) {
       float* const ot = out + n0 * L;
+      AMBER_REPIN_H4;
       if (nstore == kTile) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -922,6 +931,7 @@ __global__ __launch_bounds__(64 * node_waves<L>()) void node_kernel_f2(const Nod
         // across the previous phase it would push the kernel over its 256 registers (432 bytes of scratch).  L <= 64: kept.
         if constexpr (L > 64 || AMBER_NODE_RELOAD_V) {
           const float* const vt = (a.do_update ? a.x_out : a.x_in) + n0 * L;
+          AMBER_REPIN_H4;
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
             const unsigned off = static_cast<unsigned>(min(8 * (i >> 2) + (i & 3) + h4, rlim) * L + nq);
