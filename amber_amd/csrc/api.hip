@@ -504,6 +504,7 @@ int forward_impl(const AmberMpnDesc* desc, const float* params, const float* pac
       ea.emb_attr = edge_attr;
       ea.emb_w = d.in_edge_features > 0 ? params + lay.edge_embed.W[0] : nullptr;
       ea.emb_b = params + lay.edge_embed.B[0];
+      ea.emb_w0 = params + lay.edge[step].W[0];
     }
     ea.write_e = (last && !tape) ? 0 : 1;  // after the last step only the aggregate (and out_edge, if asked for) is needed
     ea.out_edge = last ? out_edge : nullptr;

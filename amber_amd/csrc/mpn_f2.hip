@@ -370,10 +370,25 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
   const int n = lane & 31, h = lane >> 5;
 
   // all layer weights (hi/lo fp16, B-operand order) into LDS, once per workgroup
-  for (int m = 0; m < a.nl; ++m) {
+  for (int m = EMB ? 1 : 0; m < a.nl; ++m) {
     const f32x4* src = reinterpret_cast<const f32x4*>(m == 0 ? a.w0e : a.layers[m].w);
     f32x4* dst = reinterpret_cast<f32x4*>(smem + m * MAT_BYTES);
     for (int i = tid; i < MAT_BYTES / 16; i += 64 * edge_waves<L>()) dst[i] = src[i];
+  }
+  if constexpr (EMB) {
+    // The fused first step needs no first-layer contraction: e = emb_w attr + emb_b is linear in the raw features, so
+    // W0e e = (W0e emb_w) attr + W0e emb_b.  The folded table [kMaxFusedEmbed + 1][L] (last row: the constant) takes the
+    // place of the first matrix in LDS; every workgroup forms it once (L (F_e + 1) dot products of length L, fp32).
+    float* fold = reinterpret_cast<float*>(smem);
+    for (int o = tid; o < (kMaxFusedEmbed + 1) * L; o += 64 * edge_waves<L>()) {
+      const int k = o / L, j = o - k * L;
+      float sum = 0.f;
+      if (k < a.emb_f || k == kMaxFusedEmbed) {
+        const float* wr = a.emb_w0 + static_cast<int64_t>(j) * (3 * L) + 2 * L;
+        for (int m = 0; m < L; ++m) sum = fmaf(wr[m], k == kMaxFusedEmbed ? a.emb_b[m] : a.emb_w[m * a.emb_f + k], sum);
+      }
+      fold[o] = sum;
+    }
   }
   __syncthreads();
   unsigned char* win = smem + a.nl * MAT_BYTES + wave * kWinBytes;
@@ -476,6 +491,30 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
         }
       }
     };
+    // t += (W0e emb_w) attr + W0e emb_b from the folded table (see the prologue)
+    auto fold_tile_add = [&](Tile<L>& t) {
+      const float* fold = reinterpret_cast<const float*>(smem);
+      float wq[NFB][kMaxFusedEmbed], bq[NFB];
+#pragma unroll
+      for (int fb = 0; fb < NFB; ++fb) {
+        bq[fb] = fold[kMaxFusedEmbed * L + 32 * fb + nq];
+#pragma unroll
+        for (int k = 0; k < kMaxFusedEmbed; ++k) wq[fb][k] = fold[k * L + 32 * fb + nq];
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        float ev[kMaxFusedEmbed];
+#pragma unroll
+        for (int k = 0; k < kMaxFusedEmbed; ++k) ev[k] = __int_as_float(tile_row_value<L>(__float_as_int(eav[k]), i, h));
+#pragma unroll
+        for (int fb = 0; fb < NFB; ++fb) {
+          float v = bq[fb];
+#pragma unroll
+          for (int k = 0; k < kMaxFusedEmbed; ++k) v = fmaf(ev[k], wq[fb][k], v);
+          t.a[fb][i] += v;
+        }
+      }
+    };
     // ---- streamed e rows (whole row pieces; PIPE: issued during the previous tile's epilogue) and gathered
     // first-layer terms, straight into the accumulator layout ----
     if constexpr (!EMB && !PIPE) load_e(tile);
@@ -492,22 +531,18 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
     if (nvalid < kTile) newseg &= (1u << nvalid) - 1u;
 
     // ---- layer 0: acc = (P_s + P_d) + W0e e, in the scaled domain ----
-    float scale, inv;
+    float scale = 1.f, inv = 1.f, us = 1.f;
     if constexpr (EMB) {
-      Tile<L> e0;
-      embed_tile(e0);
-      pow2_scale(wave_max(tile_absmax<L>(e0)), scale, inv);
-      tile_scale<L>(acc, scale * wscale0);
-      gemm_acc<L, SPLIT>(acc, e0, scale, win, wo, smem, lane);
+      fold_tile_add(acc);  // exact fp32, no scaled domain
     } else {
       pow2_scale(wave_max(landing_absmax<L>(la)), scale, inv);
       tile_scale<L>(acc, scale * wscale0);
       if (!DBG(8)) gemm_rows<L, SPLIT>(acc, la, scale, win, wo, smem, lane);
+      us = inv * wsinv0;
     }
     // destination terms (rows repeat inside a tile: L1 / L2 hits) join after the contraction, when the landing
     // registers of e are free again
     {
-      const float us = inv * wsinv0;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int di = tile_row_value<L>(d0, i, h);
@@ -1109,7 +1144,7 @@ static hipError_t launch_edge_f2_l(const EdgeArgs& a, int num_cus, hipStream_t s
 
 hipError_t launch_edge_f2(int L, const EdgeArgs& a, int num_cus, hipStream_t s) {
   if (a.E == 0) return hipSuccess;
-  if (a.emb_on && (a.emb_f < 0 || a.emb_f > kMaxFusedEmbed || !a.emb_b || !a.perm)) return hipErrorInvalidValue;
+  if (a.emb_on && (a.emb_f < 0 || a.emb_f > kMaxFusedEmbed || !a.emb_b || !a.emb_w0 || !a.perm)) return hipErrorInvalidValue;
   switch (L) {
     case 32: return launch_edge_f2_l<32>(a, num_cus, s);
     case 64: return launch_edge_f2_l<64>(a, num_cus, s);

@@ -52,6 +52,8 @@ struct EdgeArgs {
   const float* emb_attr;  // [E, emb_f] raw edge features, edge_index order
   const float* emb_w;     // [L, emb_f]
   const float* emb_b;     // [L]
+  const float* emb_w0;    // [L, 3L] fp32 first-layer weight of this step's edge MLP: the fused step folds its e block with the
+                          // embedding, W0e (emb_w attr + emb_b) = (W0e emb_w) attr + W0e emb_b, so layer 0 needs no contraction
   int32_t emb_f;          // 0 .. kMaxFusedEmbed
   int32_t emb_on;
   int32_t single;         // AMBER_PREC_F16: plain fp16 operands (one MFMA a product) instead of the hi/lo split
