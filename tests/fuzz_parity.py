@@ -153,6 +153,9 @@ def main():
                 out = model(gb)
                 (out * grad_out.to(dev)).sum().backward()
                 errs = {k: rel_err(p.grad.cpu(), g32[k]) for k, p in model.named_parameters()}
+                # the readout bias gradient is the plain sum of grad_out: one number, which can cancel to nothing - measure
+                # its error against the size of the terms
+                errs["readout.bias"] = float((model.readout.bias.grad.cpu() - g32["readout.bias"]).abs().max()) / float(grad_out.abs().sum())
                 kmax = max(errs, key=errs.get)
                 ferr = rel_err(out.detach().cpu(), want)
                 # gradients are sums over all rows in another order than the oracle's: up to ~7x the oracle's own float32 noise seen
