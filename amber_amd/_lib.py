@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("AMBER_MPN_LIB") or os.path.join(_HERE, "csrc", "libam
 MAX_MLP_LAYERS = 4
 TILE = 32
 NUM_KERNEL_CLASSES = 4
+CSR_STATIC_SCRATCH_BYTES = 16 << 20  # AMBER_MPN_CSR_STATIC_SCRATCH_BYTES
 
 ACT = {"relu": 0, "leakyrelu": 1, "tanh": 2, "elu": 3, "swish": 4, "silu": 4, "mish": 5, "gelu": 6}
 MODE = {None: 0, "none": 0, "inner": 1, "outer": 2}
@@ -85,6 +86,7 @@ SIGNATURES = {
     "amber_mpn_pack_weights": (C.c_int, [_DESC, _P, _P, _P]),
     "amber_mpn_csr_workspace_bytes": (_SZ, [_I64, _I64]),
     "amber_mpn_csr_build": (C.c_int, [_P, _I64, _I64, _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    "amber_mpn_csr_build_static": (C.c_int, [_P, _I64, _I64, _P, _P, _P, _P, _P, _P]),
     "amber_mpn_segment_mean": (C.c_int, [_P, _P, _I64, _I64, _I32, _P, _P]),
     "amber_mpn_permute_rows": (C.c_int, [_P, _P, _I64, _I32, _I32, _P, _P]),
     "amber_mpn_workspace_bytes": (_SZ, [_DESC, _I64, _I64]),

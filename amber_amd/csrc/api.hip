@@ -944,6 +944,28 @@ int amber_mpn_csr_build(const int64_t* edge_index, int64_t num_edges, int64_t nu
   return AMBER_OK;
 }
 
+int amber_mpn_csr_build_static(const int64_t* edge_index, int64_t num_edges, int64_t num_nodes, int32_t* rowptr,
+                               int32_t* src_sorted, int32_t* dst_sorted, int32_t* perm, int32_t* status, void* stream) {
+  if (num_nodes < 0 || num_edges < 0 || num_nodes >= (1ll << 31) || num_edges >= (1ll << 31))
+    return fail(AMBER_ERR_INVALID_ARGUMENT, "num_nodes / num_edges out of int32 range");
+  if (!rowptr || !status) return fail(AMBER_ERR_INVALID_ARGUMENT, "rowptr / status is NULL");
+  if (num_edges > 0 && (!edge_index || !src_sorted || !dst_sorted || !perm))
+    return fail(AMBER_ERR_INVALID_ARGUMENT, "edge arrays are NULL");
+  if (num_edges > 0 && num_nodes == 0) return fail(AMBER_ERR_INVALID_ARGUMENT, "edges without nodes");
+  const size_t need = csr_workspace_bytes(num_nodes, num_edges);
+  if (need > static_cast<size_t>(AMBER_MPN_CSR_STATIC_SCRATCH_BYTES))
+    return fail(AMBER_ERR_WORKSPACE_TOO_SMALL,
+                "graph needs %zu bytes of CSR scratch, the static array holds %zu (use amber_mpn_csr_build with a workspace)", need,
+                static_cast<size_t>(AMBER_MPN_CSR_STATIC_SCRATCH_BYTES));
+  (void)hipGetLastError();
+  void* ws = nullptr;
+  HIP_TRY(csr_static_scratch(&ws), "address of the static CSR scratch");
+  HIP_TRY(csr_build(edge_index, num_edges, num_nodes, rowptr, src_sorted, dst_sorted, perm, status, ws,
+                    static_cast<hipStream_t>(stream)),
+          "csr_build (static scratch)");
+  return AMBER_OK;
+}
+
 int amber_mpn_segment_mean(const float* values_sorted, const int32_t* rowptr, int64_t num_nodes, int64_t num_edges, int32_t latent,
                            float* out, void* stream) {
   if (num_nodes < 0 || num_edges < 0) return fail(AMBER_ERR_INVALID_ARGUMENT, "negative size");

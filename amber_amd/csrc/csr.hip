@@ -10,7 +10,15 @@
 //                (src/mpn/message_passing_modules.py:67-68).  Short rows: one thread, insertion sort;
 //                long rows (hub nodes of hierarchical graphs): one wave, rank counting.
 //   5. gather  : src_sorted / dst_sorted
+#include <mutex>
+
 #include "mpn_internal.h"
+
+// Scratch of the allocation-free entry point amber_mpn_csr_build_static (include/amber_mpn.h): the count | cursor |
+// chunk_sum | slots areas that amber_mpn_csr_build takes from the caller's workspace.  One copy per GPU the library runs
+// on, held until the process ends.  Host code never uses this name as an address: csr_static_scratch() asks the runtime
+// for each device's copy once and hands that pointer on.
+static __device__ __align__(256) unsigned char scratch[AMBER_MPN_CSR_STATIC_SCRATCH_BYTES];
 
 namespace amber {
 
@@ -181,6 +189,28 @@ size_t csr_workspace_bytes(int64_t N, int64_t E) {
   const int64_t nchunks = cdiv(N > 0 ? N : 1, kScanChunk);
   return align256(sizeof(int32_t) * static_cast<size_t>(N)) * 2 + align256(sizeof(int32_t) * static_cast<size_t>(nchunks)) +
          align256(sizeof(int32_t) * static_cast<size_t>(E));
+}
+
+// Device address of this GPU's copy of `scratch` (looked up once per device, with that device current).
+hipError_t csr_static_scratch(void** out) {
+  constexpr int kMaxDevices = 64;
+  static std::mutex mu;
+  static void* ptr_of[kMaxDevices] = {};
+  *out = nullptr;
+  int dev = 0;
+  hipError_t err = hipGetDevice(&dev);
+  if (err != hipSuccess) return err;
+  if (dev < 0 || dev >= kMaxDevices) return hipErrorInvalidDevice;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!ptr_of[dev]) {
+    void* p = nullptr;
+    err = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (err != hipSuccess) return err;
+    if (!p) return hipErrorInvalidSymbol;
+    ptr_of[dev] = p;
+  }
+  *out = ptr_of[dev];
+  return hipSuccess;
 }
 
 hipError_t csr_build(const int64_t* edge_index, int64_t E, int64_t N, int32_t* rowptr, int32_t* src_sorted,

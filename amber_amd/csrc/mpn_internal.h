@@ -271,5 +271,7 @@ hipError_t launch_inter_edges(const GraphArgs& a, const int64_t* nearest, const 
 size_t csr_workspace_bytes(int64_t N, int64_t E);
 hipError_t csr_build(const int64_t* edge_index, int64_t E, int64_t N, int32_t* rowptr, int32_t* src_sorted,
                      int32_t* dst_sorted, int32_t* perm, int32_t* status, void* ws, hipStream_t s);
+// this GPU's copy of the file-scope scratch array of csr.hip (AMBER_MPN_CSR_STATIC_SCRATCH_BYTES), 256-byte aligned
+hipError_t csr_static_scratch(void** out);
 
 }  // namespace amber

@@ -127,6 +127,17 @@ int amber_mpn_csr_build(const int64_t* edge_index, int64_t num_edges, int64_t nu
                         int32_t* src_sorted, int32_t* dst_sorted, int32_t* perm, int32_t* status, void* workspace,
                         size_t workspace_bytes, void* stream);
 
+/* amber_mpn_csr_build without a workspace argument and without any allocation.  No counterpart in the reference: it is
+ * for callers that cannot allocate device memory around the call (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  The count / cursor / scan / slot areas live in a file-scope device array of
+ * AMBER_MPN_CSR_STATIC_SCRATCH_BYTES that every GPU the library runs on holds until the process ends; graphs with
+ * amber_mpn_csr_workspace_bytes(num_nodes, num_edges) - 256 above that are rejected (AMBER_ERR_WORKSPACE_TOO_SMALL).
+ * Same outputs as amber_mpn_csr_build, bit for bit.  All calls on one GPU share that GPU's array: calls that overlap
+ * on one GPU (different streams or threads) race; calls on one stream are ordered and each clears what it needs. */
+#define AMBER_MPN_CSR_STATIC_SCRATCH_BYTES (16u << 20)
+int amber_mpn_csr_build_static(const int64_t* edge_index, int64_t num_edges, int64_t num_nodes, int32_t* rowptr,
+                               int32_t* src_sorted, int32_t* dst_sorted, int32_t* perm, int32_t* status, void* stream);
+
 /* Deterministic segmented mean over CSR rows, no float atomics: out[n] = sum(values[rowptr[n]:rowptr[n+1]]) /
  * max(deg, 1), summed in row order.  Replaces torch_scatter.scatter_mean at
  * src/mpn/message_passing_modules.py:68 (values already destination-sorted).  L % 4 == 0, L <= 1024. */
