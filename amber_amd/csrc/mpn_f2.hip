@@ -139,18 +139,33 @@ DEVINL void round4(const f32x4 x, float scale, half4& hi) {
   }
   hi = __builtin_bit_cast(half4, hh);
 }
-// value that lane c (= tile row c) holds in `v`, for the row of accumulator register i in this lane's half: row
-// 8 (i >> 2) + (i & 3) + 4 h.  L = 128: two v_readlane (the rows are compile-time constants) and a select by half
-// instead of a ds_bpermute - same time, 13 registers fewer (the fused-embedding variant stops spilling).  L <= 64, where
-// a row is only one or two loads, the scalar detour costs more than it saves (measured: +50 % per launch): ds_bpermute.
-template <int L>
-DEVINL int tile_row_value(int v, int i, int h) {
-  if constexpr (L >= 128) {
-    const int lo = __builtin_amdgcn_readlane(v, 8 * (i >> 2) + (i & 3));
-    const int hi = __builtin_amdgcn_readlane(v, 8 * (i >> 2) + (i & 3) + 4);
-    return h ? hi : lo;
-  } else {
-    return __shfl(v, 8 * (i >> 2) + (i & 3) + 4 * h);
+// Row indices for the direct row accesses.  Register i of lane (h, n) holds tile row 8 (i >> 2) + (i & 3) + 4 h, the same
+// row for all 32 lanes of a half, so its index (source / destination node, output row) is needed in every lane of the
+// half.  The lane that holds it: lane i of each row of 16 lanes, when that lane loaded the index of row tile_xrow(lane) -
+// then ONE DPP move (row_newbcast:i, gfx90a+) delivers it, instead of two v_readlane, two moves and a select.
+DEVINL int tile_xrow(int lane) { return 8 * ((lane & 15) >> 2) + (lane & 3) + 4 * (lane >> 5); }
+template <int I>
+DEVINL int row_bcast_c(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, 0x150 + I, 0xf, 0xf, true);  // row_newbcast:I
+}
+DEVINL int row_bcast(int v, int i) {  // i: a constant after unrolling
+  switch (i) {
+    case 0: return row_bcast_c<0>(v);
+    case 1: return row_bcast_c<1>(v);
+    case 2: return row_bcast_c<2>(v);
+    case 3: return row_bcast_c<3>(v);
+    case 4: return row_bcast_c<4>(v);
+    case 5: return row_bcast_c<5>(v);
+    case 6: return row_bcast_c<6>(v);
+    case 7: return row_bcast_c<7>(v);
+    case 8: return row_bcast_c<8>(v);
+    case 9: return row_bcast_c<9>(v);
+    case 10: return row_bcast_c<10>(v);
+    case 11: return row_bcast_c<11>(v);
+    case 12: return row_bcast_c<12>(v);
+    case 13: return row_bcast_c<13>(v);
+    case 14: return row_bcast_c<14>(v);
+    default: return row_bcast_c<15>(v);
   }
 }
 // sum over the 32 lanes of a half-wave, result in every lane of the half
@@ -331,6 +346,24 @@ DEVINL float landing_absmax(const ELanding<L>& la) {
       for (int t = 0; t < 4; ++t) m = fmaxf(m, fabsf(la.v[ps][it][t]));
   return m;
 }
+// half_sum of sixteen values at once, step by step over all of them: a DPP operand needs two wait states after the
+// instruction that wrote it, and one value's five steps are a dependent chain - taken one value at a time the compiler
+// filled the hazards with s_nop (173 of them in one LayerNorm)
+DEVINL void half_sum16(float (&v)[16]) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i) v[i] += AMBER_DPP_F(v[i], 0xB1);   // quad_perm [1,0,3,2]
+#pragma unroll
+  for (int i = 0; i < 16; ++i) v[i] += AMBER_DPP_F(v[i], 0x4E);   // quad_perm [2,3,0,1]
+#pragma unroll
+  for (int i = 0; i < 16; ++i) v[i] += AMBER_DPP_F(v[i], 0x141);  // row_half_mirror
+#pragma unroll
+  for (int i = 0; i < 16; ++i) v[i] += AMBER_DPP_F(v[i], 0x140);  // row_mirror
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[i]), __float_as_uint(v[i]), false, false);
+    v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+}
 // LayerNorm over the features of every row of a tile in accumulator layout: across the lanes of a half, one register a row
 template <int L>
 DEVINL void tile_layernorm_acc(Tile<L>& acc, const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int n) {
@@ -341,12 +374,17 @@ DEVINL void tile_layernorm_acc(Tile<L>& acc, const float* __restrict__ gamma, co
     g[fb] = gamma[32 * fb + n];
     bt[fb] = beta[32 * fb + n];
   }
+  float s[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
-    float s = acc.a[0][i];
+    s[i] = acc.a[0][i];
 #pragma unroll
-    for (int fb = 1; fb < NFB; ++fb) s += acc.a[fb][i];
-    const float mean = half_sum(s) * (1.0f / L);
+    for (int fb = 1; fb < NFB; ++fb) s[i] += acc.a[fb][i];
+  }
+  half_sum16(s);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const float mean = s[i] * (1.0f / L);
     float q = 0.f;
 #pragma unroll
     for (int fb = 0; fb < NFB; ++fb) {
@@ -354,7 +392,12 @@ DEVINL void tile_layernorm_acc(Tile<L>& acc, const float* __restrict__ gamma, co
       acc.a[fb][i] = dlt;
       q += dlt * dlt;
     }
-    const float rstd = __builtin_amdgcn_rsqf(half_sum(q) * (1.0f / L) + eps);  // v_rsq_f32: 1 ulp
+    s[i] = q;
+  }
+  half_sum16(s);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const float rstd = __builtin_amdgcn_rsqf(s[i] * (1.0f / L) + eps);  // v_rsq_f32: 1 ulp
 #pragma unroll
     for (int fb = 0; fb < NFB; ++fb) acc.a[fb][i] = acc.a[fb][i] * rstd * g[fb] + bt[fb];
   }
@@ -406,18 +449,20 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
   const int64_t stride = bpx * edge_waves<L>();
   int64_t tile = t_begin + local * edge_waves<L>() + wave;
 
-  // lane c (both halves) holds source / destination of tile row c; the next tile's are loaded ahead
-  int s0 = 0, d0 = 0, s1 = 0, d1 = 0;
-  auto load_idx = [&](int64_t t, int& s, int& d) {
-    int64_t p = t * kTile + n;
-    if (p > a.E - 1) p = a.E - 1;  // rows beyond the end repeat the last edge and are never stored
-    s = a.src[p];
+  // d: lane c (both halves) holds the destination of tile row c (row boundaries of the per-destination sums); sx / dx:
+  // source / destination of row tile_xrow(lane), the form the row broadcasts read (see row_bcast).  The next tile's are
+  // loaded a tile ahead.
+  const int xr = tile_xrow(lane);
+  int sx0 = 0, d0 = 0, dx0 = 0, sx1 = 0, d1 = 0, dx1 = 0;
+  auto load_idx = [&](int64_t t, int& sx, int& d, int& dx) {
+    const int64_t q = t * kTile, last = a.E - 1;
+    const int64_t p = q + n < last ? q + n : last;  // rows beyond the end repeat the last edge and are never stored
+    const int64_t px = q + xr < last ? q + xr : last;
     d = a.dst[p];
+    sx = a.src[px];
+    dx = a.dst[px];
   };
-  if (tile < t_end) {
-    load_idx(tile, s0, d0);
-    if (tile + stride < t_end) load_idx(tile + stride, s1, d1);
-  }
+  if (tile < t_end) load_idx(tile, sx0, d0, dx0);
   // Software pipeline over the tiles of a wave (PIPE): the rows of e that open a tile are loaded during the PREVIOUS
   // tile's epilogue (LayerNorm, stores, per-destination sums), when the landing registers of the hidden layer are free,
   // so their latency runs under that work.  Measured at L = 64: -2.4 % per launch (L = 32: +30 %, off).  At L = 128 the 64 loop-carried
@@ -438,11 +483,12 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
       for (int ps = 0; ps < NFB; ++ps) la.v[ps][it] = p[ps * 8];
     }
   };
-  auto gather_ps = [&](int sidx) {
+  auto gather_ps = [&](int sidx, int nq) {
+    const float* const psn = a.Ps + nq;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      const int si = tile_row_value<L>(sidx, i, h);
-      const float* ps = a.Ps + static_cast<int64_t>(DBG(32) ? 0 : si) * L + n;
+      const unsigned si = static_cast<unsigned>(row_bcast(sidx, i));
+      const float* ps = psn + static_cast<size_t>(DBG(32) ? 0u : si) * L;
 #pragma unroll
       for (int fb = 0; fb < NFB; ++fb) pn.a[fb][i] = ps[32 * fb];
     }
@@ -460,9 +506,9 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
     asm volatile("" : "+v"(hq), "+v"(nq));
     // ---- first step with the edge embedding fused in: the rows of e are computed, not read (K1: Embedding.forward,
     // src/mpn/common/embedding.py:44-54, linear form) - directly in accumulator layout ----
-    float eav[kMaxFusedEmbed] = {0.f, 0.f, 0.f, 0.f};  // lane c (both halves): raw features of tile row c
+    float eav[kMaxFusedEmbed] = {0.f, 0.f, 0.f, 0.f};  // raw features of tile row tile_xrow(lane) (see row_bcast)
     if (EMB && a.emb_f > 0) {
-      int64_t p = p0 + n;
+      int64_t p = p0 + xr;
       if (p > a.E - 1) p = a.E - 1;
       const float* pa = a.emb_attr + static_cast<int64_t>(a.perm[p]) * a.emb_f;
 #pragma unroll
@@ -481,7 +527,7 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
       for (int i = 0; i < 16; ++i) {
         float ev[kMaxFusedEmbed];
 #pragma unroll
-        for (int k = 0; k < kMaxFusedEmbed; ++k) ev[k] = __int_as_float(tile_row_value<L>(__float_as_int(eav[k]), i, h));
+        for (int k = 0; k < kMaxFusedEmbed; ++k) ev[k] = __int_as_float(row_bcast(__float_as_int(eav[k]), i));
 #pragma unroll
         for (int fb = 0; fb < NFB; ++fb) {
           float v = bq[fb];
@@ -505,7 +551,7 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
       for (int i = 0; i < 16; ++i) {
         float ev[kMaxFusedEmbed];
 #pragma unroll
-        for (int k = 0; k < kMaxFusedEmbed; ++k) ev[k] = __int_as_float(tile_row_value<L>(__float_as_int(eav[k]), i, h));
+        for (int k = 0; k < kMaxFusedEmbed; ++k) ev[k] = __int_as_float(row_bcast(__float_as_int(eav[k]), i));
 #pragma unroll
         for (int fb = 0; fb < NFB; ++fb) {
           float v = bq[fb];
@@ -518,10 +564,9 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
     // ---- streamed e rows (whole row pieces; PIPE: issued during the previous tile's epilogue) and gathered
     // first-layer terms, straight into the accumulator layout ----
     if constexpr (!EMB && !PIPE) load_e(tile);
-    gather_ps(s0);
+    gather_ps(sx0, nq);
     Tile<L> acc = pn;
-    int s2 = 0, d2 = 0;
-    if (tile + 2 * stride < t_end) load_idx(tile + 2 * stride, s2, d2);
+    if (tile + stride < t_end) load_idx(tile + stride, sx1, d1, dx1);
     const int firstd = __builtin_amdgcn_readlane(d0, 0);
     const int lastd = __builtin_amdgcn_readlane(d0, nvalid - 1);
     const int rp_first = a.rowptr[firstd], rp_last = a.rowptr[lastd + 1];
@@ -543,10 +588,11 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
     // destination terms (rows repeat inside a tile: L1 / L2 hits) join after the contraction, when the landing
     // registers of e are free again
     {
+      const float* const pdn = a.Pd + nq;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const int di = tile_row_value<L>(d0, i, h);
-        const float* pd = a.Pd + static_cast<int64_t>(DBG(2) ? 0 : di) * L + n;
+        const unsigned di = static_cast<unsigned>(row_bcast(dx0, i));
+        const float* pd = pdn + static_cast<size_t>(DBG(2) ? 0u : di) * L;
 #pragma unroll
         for (int fb = 0; fb < NFB; ++fb) acc.a[fb][i] = fmaf(acc.a[fb][i], us, pd[32 * fb]);
       }
@@ -580,13 +626,26 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
       embed_tile(e0);
       tile_add<L>(acc, e0);
     } else if (!EMB && a.residual == AMBER_MODE_INNER && !DBG(1)) {
+      if (nvalid == kTile) {
+        // one 64-bit address per group of four registers; the rows and feature blocks inside it are immediate offsets
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        // rows beyond the end repeat the last edge
-        const unsigned off = nvalid == kTile ? static_cast<unsigned>(hq + (8 * (i >> 2) + (i & 3)) * L)
-                                             : static_cast<unsigned>(min(8 * (i >> 2) + (i & 3) + 4 * h, rlim) * L + n);
+        for (int g = 0; g < 4; ++g) {
+          const float* const pg = et + static_cast<unsigned>(hq) + 8 * g * L;
 #pragma unroll
-        for (int fb = 0; fb < NFB; ++fb) acc.a[fb][i] += et[off + 32 * fb];
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int fb = 0; fb < NFB; ++fb) acc.a[fb][4 * g + j] += pg[j * L + 32 * fb];
+        }
+      } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            // rows beyond the end repeat the last edge
+            const float* const pr = et + static_cast<unsigned>(min(8 * g + j + 4 * h, rlim) * L + n);
+#pragma unroll
+            for (int fb = 0; fb < NFB; ++fb) acc.a[fb][4 * g + j] += pr[32 * fb];
+          }
       }
     }
     if constexpr (PIPE) {  // the next tile's opening loads, behind which the rest of this tile runs
@@ -600,25 +659,19 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
     if (a.write_e || a.out_edge) {
       int pm = 0;
       if (a.out_edge) {
-        int64_t p = p0 + n;
+        int64_t p = p0 + xr;
         if (p > a.E - 1) p = a.E - 1;
         pm = a.perm[p];
       }
       if (a.write_e && !DBG(16)) {
-        if (nvalid == kTile) {
 #pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const unsigned off = static_cast<unsigned>(hq + (8 * (i >> 2) + (i & 3)) * L);
+        for (int g = 0; g < 4; ++g) {
+          float* const pg = eo + static_cast<unsigned>(hq) + 8 * g * L;  // one address per four registers, see the residual
 #pragma unroll
-            for (int fb = 0; fb < NFB; ++fb) eo[off + 32 * fb] = acc.a[fb][i];
-          }
-        } else {
+          for (int j = 0; j < 4; ++j) {
+            if (nvalid == kTile || 8 * g + j + 4 * h < nvalid) {
 #pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const int r = 8 * (i >> 2) + (i & 3) + 4 * h;
-            if (r < nvalid) {
-#pragma unroll
-              for (int fb = 0; fb < NFB; ++fb) eo[static_cast<unsigned>(hq + (8 * (i >> 2) + (i & 3)) * L) + 32 * fb] = acc.a[fb][i];
+              for (int fb = 0; fb < NFB; ++fb) pg[j * L + 32 * fb] = acc.a[fb][4 * g + j];
             }
           }
         }
@@ -627,9 +680,9 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int r = 8 * (i >> 2) + (i & 3) + 4 * h;
-          const int orow = tile_row_value<L>(pm, i, h);
+          const unsigned orow = static_cast<unsigned>(row_bcast(pm, i));
           if (r < nvalid) {
-            float* po = a.out_edge + static_cast<int64_t>(orow) * L + n;
+            float* po = a.out_edge + static_cast<size_t>(orow) * L + n;
 #pragma unroll
             for (int fb = 0; fb < NFB; ++fb) po[32 * fb] = acc.a[fb][i];
           }
@@ -677,8 +730,9 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
       flush((!sb && ends_last) ? a.agg + static_cast<int64_t>(lastd) * L : (sb ? a.head + tile * L : a.tail + tile * L));
       }
     }
-    s0 = s1; d0 = d1;
-    s1 = s2; d1 = d2;
+    sx0 = sx1;
+    d0 = d1;
+    dx0 = dx1;
   }
 }
 
