@@ -282,7 +282,7 @@ int device_cus() {
 }
 hipError_t run_edge(const AmberMpnDesc& d, EdgeArgs& ea, hipStream_t s) {
   if (use_fast_edge(d)) {
-    ea.red_shift = 5;
+    ea.red_shift = 4;  // the split-precision kernel sums per half of a tile: reduction tiles of 16 edges
     ea.single = d.precision == AMBER_PREC_F16 ? 1 : 0;
     return launch_edge_f2(d.latent, ea, device_cus(), s);
   }
@@ -343,7 +343,7 @@ void fill_node_update(NodeArgs& a, const AmberMpnDesc& d, const Layout& lay, int
   a.nl = d.mlp_layers;
   a.act = d.activation;
   for (int l = 1; l < d.mlp_layers; ++l) a.layers[l] = DenseLayer{packed + m.PW[l][0], params + m.B[l], nullptr, nullptr};
-  a.red_shift = 5;
+  a.red_shift = use_fast_edge(d) ? 4 : 5;  // must match the edge kernel that wrote head / tail (run_edge)
   a.residual = d.residual;
   a.layer_norm = d.layer_norm;
   a.gamma = d.layer_norm != AMBER_MODE_NONE ? params + lay.ng[step] : nullptr;

@@ -139,11 +139,15 @@ DEVINL void round4(const f32x4 x, float scale, half4& hi) {
   }
   hi = __builtin_bit_cast(half4, hh);
 }
-// Row indices for the direct row accesses.  Register i of lane (h, n) holds tile row 8 (i >> 2) + (i & 3) + 4 h, the same
-// row for all 32 lanes of a half, so its index (source / destination node, output row) is needed in every lane of the
-// half.  The lane that holds it: lane i of each row of 16 lanes, when that lane loaded the index of row tile_xrow(lane) -
-// then ONE DPP move (row_newbcast:i, gfx90a+) delivers it, instead of two v_readlane, two moves and a select.
-DEVINL int tile_xrow(int lane) { return 8 * ((lane & 15) >> 2) + (lane & 3) + 4 * (lane >> 5); }
+// Row indices for the direct row accesses.  Register i of lane (h, n) holds one tile row, the same row for all 32 lanes
+// of a half, so its index (source / destination node, output row) is needed in every lane of the half.  The lane that
+// holds it: lane i of each row of 16 lanes, when that lane loaded the index of row tile_xrow(lane) - then ONE DPP move
+// (row_newbcast:i, gfx90a+) delivers it, instead of two v_readlane, two moves and a select.
+// Edge tiles: register i of half h is CSR POSITION 16 h + i of the tile (edge_pos); the MFMA's row 8 (i >> 2) + (i & 3) +
+// 4 h is only the slot the position occupies in the operand images (load_e places it there).  Each half of a wave then
+// owns sixteen consecutive edges: the direct row accesses of a half are one address and immediate offsets, and the
+// per-destination sums run over a lane's own registers with no exchange between the halves.
+DEVINL int tile_xrow(int lane) { return 16 * (lane >> 5) + (lane & 15); }
 template <int I>
 DEVINL int row_bcast_c(int v) {
   return __builtin_amdgcn_update_dpp(0, v, 0x150 + I, 0xf, 0xf, true);  // row_newbcast:I
@@ -186,6 +190,10 @@ DEVINL float half_sum(float v) {
 DEVINL half4 lds_read_tr(const unsigned char* p) {
   return __builtin_bit_cast(half4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p)));
 }
+
+// consecutive rows of L floats whose byte offsets (plus a feature block's) fit the 12-bit immediate of a global access
+template <int L>
+constexpr int kRowGroup = L >= 128 ? 8 : 16;
 
 // streamed rows of the e tile as whole row pieces: v[pass][it] = e[row it*8 + lane/8][32 pass + 4 (lane % 8) .. +3]
 template <int L>
@@ -438,7 +446,6 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
 
   const WinOff wo = make_win_off(lane);
   const float wsinv0 = a.w0e[L * L], wscale0 = a.w0e[L * L + 1];  // pack-time power-of-two weight scale (matrix header)
-  const float mh0 = h == 0 ? 1.f : 0.f, mh1 = 1.f - mh0;
 
   // XCD-aware persistent schedule: blocks b, b+8, ... share an XCD (round-robin dispatch); each XCD walks one
   // contiguous eighth of the tiles with its waves side by side, so gathered P_s rows are shared in that L2.
@@ -475,9 +482,10 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
     const int64_t q0 = t * kTile;
     const int lim = ((a.E - q0) < kTile ? static_cast<int>(a.E - q0) : kTile) - 1;
     const float* const base = a.e + q0 * L;
+    const int rb = 16 * h + ((lane >> 3) & 3);  // operand row it * 8 + lane / 8 holds position 16 h + 4 it + (lane / 8) % 4
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
-      const int r = it * 8 + (lane >> 3);
+      const int r = rb + 4 * it;
       const f32x4* p = reinterpret_cast<const f32x4*>(base + static_cast<unsigned>((r < lim ? r : lim) * L)) + (lane & 7);
 #pragma unroll
       for (int ps = 0; ps < NFB; ++ps) la.v[ps][it] = p[ps * 8];
@@ -502,7 +510,7 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
     const int rlim = nvalid - 1;
     // Lane offsets of the direct row accesses are recomputed per tile from these opaque copies: hoisted out of the tile
     // loop they would occupy dozens of registers for its whole length.
-    int hq = 4 * h * L + n, nq = n;
+    int hq = 16 * h * L + n, nq = n;  // first row of this lane's half, its feature column
     asm volatile("" : "+v"(hq), "+v"(nq));
     // ---- first step with the edge embedding fused in: the rows of e are computed, not read (K1: Embedding.forward,
     // src/mpn/common/embedding.py:44-54, linear form) - directly in accumulator layout ----
@@ -567,10 +575,17 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
     gather_ps(sx0, nq);
     Tile<L> acc = pn;
     if (tile + stride < t_end) load_idx(tile + stride, sx1, d1, dx1);
-    const int firstd = __builtin_amdgcn_readlane(d0, 0);
-    const int lastd = __builtin_amdgcn_readlane(d0, nvalid - 1);
+    // The per-destination sums run per HALF over its own sixteen positions (reduction tiles of 16 edges, red_shift 4):
+    // first / last destination of this half's positions and where their rows begin / end
+    const int nvh = nvalid - 16 * h < 0 ? 0 : (nvalid - 16 * h > 16 ? 16 : nvalid - 16 * h);  // positions of this half that exist
+    const int firstd = row_bcast(dx0, 0);
+    int lastd;
+    if (nvalid == kTile)
+      lastd = row_bcast(dx0, 15);
+    else
+      lastd = __shfl(d0, nvh > 0 ? 16 * h + nvh - 1 : 0);
     const int rp_first = a.rowptr[firstd], rp_last = a.rowptr[lastd + 1];
-    // bit r: row r of the tile begins a new destination (wave-uniform); rows beyond the end never do
+    // bit r: position r of the tile begins a new destination (wave-uniform); positions beyond the end never do
     const int dprev = __shfl_up(d0, 1);  // every lane takes part: the shuffle must not sit behind the n > 0 test
     unsigned newseg = static_cast<unsigned>(__ballot((d0 != dprev) & (n > 0)));
     if (nvalid < kTile) newseg &= (1u << nvalid) - 1u;
@@ -627,25 +642,23 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
       tile_add<L>(acc, e0);
     } else if (!EMB && a.residual == AMBER_MODE_INNER && !DBG(1)) {
       if (nvalid == kTile) {
-        // one 64-bit address per group of four registers; the rows and feature blocks inside it are immediate offsets
+        // one 64-bit address per group of registers; the rows and feature blocks inside it are immediate offsets
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const float* const pg = et + static_cast<unsigned>(hq) + 8 * g * L;
+        for (int g = 0; g < 16 / kRowGroup<L>; ++g) {
+          const float* const pg = et + static_cast<unsigned>(hq) + kRowGroup<L> * g * L;
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
+          for (int j = 0; j < kRowGroup<L>; ++j)
 #pragma unroll
-            for (int fb = 0; fb < NFB; ++fb) acc.a[fb][4 * g + j] += pg[j * L + 32 * fb];
+            for (int fb = 0; fb < NFB; ++fb) acc.a[fb][kRowGroup<L> * g + j] += pg[j * L + 32 * fb];
         }
       } else {
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
+        for (int i = 0; i < 16; ++i) {
+          // rows beyond the end repeat the last edge
+          const float* const pr = et + static_cast<unsigned>(min(i + 16 * h, rlim) * L + n);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            // rows beyond the end repeat the last edge
-            const float* const pr = et + static_cast<unsigned>(min(8 * g + j + 4 * h, rlim) * L + n);
-#pragma unroll
-            for (int fb = 0; fb < NFB; ++fb) acc.a[fb][4 * g + j] += pr[32 * fb];
-          }
+          for (int fb = 0; fb < NFB; ++fb) acc.a[fb][i] += pr[32 * fb];
+        }
       }
     }
     if constexpr (PIPE) {  // the next tile's opening loads, behind which the rest of this tile runs
@@ -665,13 +678,13 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
       }
       if (a.write_e && !DBG(16)) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          float* const pg = eo + static_cast<unsigned>(hq) + 8 * g * L;  // one address per four registers, see the residual
+        for (int g = 0; g < 16 / kRowGroup<L>; ++g) {
+          float* const pg = eo + static_cast<unsigned>(hq) + kRowGroup<L> * g * L;  // one address per group, see the residual
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            if (nvalid == kTile || 8 * g + j + 4 * h < nvalid) {
+          for (int j = 0; j < kRowGroup<L>; ++j) {
+            if (nvalid == kTile || kRowGroup<L> * g + j + 16 * h < nvalid) {
 #pragma unroll
-              for (int fb = 0; fb < NFB; ++fb) pg[j * L + 32 * fb] = acc.a[fb][4 * g + j];
+              for (int fb = 0; fb < NFB; ++fb) pg[j * L + 32 * fb] = acc.a[fb][kRowGroup<L> * g + j];
             }
           }
         }
@@ -679,7 +692,7 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
       if (a.out_edge) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          const int r = 8 * (i >> 2) + (i & 3) + 4 * h;
+          const int r = i + 16 * h;
           const unsigned orow = static_cast<unsigned>(row_bcast(pm, i));
           if (r < nvalid) {
             float* po = a.out_edge + static_cast<size_t>(orow) * L + n;
@@ -689,45 +702,53 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
         }
       }
     }
-    // ---- per-destination sums in CSR order: sums over registers, wave-uniform control flow, then the two lane
-    // halves are added; rows that lie inside the tile go to agg, cut rows to head / tail (see mpn_kernels.hip) ----
+    // ---- per-destination sums in CSR order: every lane adds up its own registers (its half's sixteen consecutive
+    // edges); a row that ends inside the half goes to agg, rows cut by the half's borders to head / tail of the
+    // reduction tile 2 tile + h (see mpn_kernels.hip); the two halves differ only in WHERE their rows end, which the
+    // wave handles by predication ----
     {
-      if (nvalid < kTile) {  // rows beyond the end do not count
+      if (nvalid < kTile) {  // positions beyond the end do not count
 #pragma unroll
         for (int i = 0; i < 16; ++i)
-          if (8 * (i >> 2) + (i & 3) + 4 * h >= nvalid) {
+          if (i + 16 * h >= nvalid) {
 #pragma unroll
             for (int fb = 0; fb < NFB; ++fb) acc.a[fb][i] = 0.f;
           }
       }
-      const bool ends_last = (p0 + nvalid) == static_cast<int64_t>(rp_last);
       if (!DBG(4)) {
-      bool sb = p0 > static_cast<int64_t>(rp_first);
-      float sum[NFB];
+        const int64_t q0 = p0 + 16 * h;
+        const bool ends_last = (q0 + nvh) == static_cast<int64_t>(rp_last);
+        bool sb = q0 > static_cast<int64_t>(rp_first);  // the half's first row began before it
+        const unsigned mybits = h ? (newseg >> 16) : (newseg & 0xffffu);
+        const unsigned anybits = (newseg | (newseg >> 16)) & 0xfffeu;  // wave-uniform: some half ends a row before position i
+        float* const slot_head = a.head + (2 * tile + h) * L + nq;
+        float* const slot_tail = a.tail + (2 * tile + h) * L + nq;
+        float* const aggn = a.agg + nq;
+        float sum[NFB];
 #pragma unroll
-      for (int fb = 0; fb < NFB; ++fb) sum[fb] = 0.f;
-      auto flush = [&](float* dstp) {
+        for (int fb = 0; fb < NFB; ++fb) sum[fb] = 0.f;
 #pragma unroll
-        for (int fb = 0; fb < NFB; ++fb) {
-          // both halves' partial sums: swap the upper half of one copy with the lower half of the other
-          const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(sum[fb]), __float_as_uint(sum[fb]), false, false);
-          const float tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
-          if (h == 0) dstp[static_cast<unsigned>(nq) + 32 * fb] = tot;
-          sum[fb] = 0.f;
+        for (int i = 0; i < 16; ++i) {
+          if (i > 0 && ((anybits >> i) & 1u)) {
+            const unsigned dp = static_cast<unsigned>(row_bcast(dx0, i - 1));  // outside the predicated part: all lanes take part
+            if ((mybits >> i) & 1u) {
+              float* const dstp = sb ? slot_head : aggn + static_cast<size_t>(dp) * L;
+#pragma unroll
+              for (int fb = 0; fb < NFB; ++fb) {
+                dstp[32 * fb] = sum[fb];
+                sum[fb] = 0.f;
+              }
+              sb = false;
+            }
+          }
+#pragma unroll
+          for (int fb = 0; fb < NFB; ++fb) sum[fb] += acc.a[fb][i];
         }
-      };
+        if (nvh > 0) {
+          float* const dstp = (!sb && ends_last) ? aggn + static_cast<size_t>(static_cast<unsigned>(lastd)) * L : (sb ? slot_head : slot_tail);
 #pragma unroll
-      for (int r = 0; r < kTile; ++r) {
-        if (r > 0 && ((newseg >> r) & 1u)) {
-          flush(sb ? a.head + tile * L : a.agg + static_cast<int64_t>(__builtin_amdgcn_readlane(d0, r - 1)) * L);
-          sb = false;
+          for (int fb = 0; fb < NFB; ++fb) dstp[32 * fb] = sum[fb];
         }
-        const int i = 4 * (r >> 3) + (r & 3);
-        const float mk = ((r >> 2) & 1) ? mh1 : mh0;
-#pragma unroll
-        for (int fb = 0; fb < NFB; ++fb) sum[fb] = fmaf(acc.a[fb][i], mk, sum[fb]);
-      }
-      flush((!sb && ends_last) ? a.agg + static_cast<int64_t>(lastd) * L : (sb ? a.head + tile * L : a.tail + tile * L));
       }
     }
     sx0 = sx1;
@@ -963,12 +984,23 @@ __global__ __launch_bounds__(64 * node_waves<L>()) void node_kernel_f2(const Nod
       // order of message_passing_block.py:124-125: inner residual, inner LayerNorm
       if (a.residual == AMBER_MODE_INNER) {
         AMBER_REPIN_H4;
+        if (nvalid == kTile) {
+          // one 64-bit address per group of four registers; rows and feature blocks inside it are immediate offsets
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const unsigned off = nvalid == kTile ? static_cast<unsigned>(hq + (8 * (i >> 2) + (i & 3)) * L)
-                                               : static_cast<unsigned>(min(8 * (i >> 2) + (i & 3) + h4, rlim) * L + n);
+          for (int g = 0; g < 4; ++g) {
+            const float* const pg = xt + static_cast<unsigned>(hq) + 8 * g * L;
 #pragma unroll
-          for (int fb = 0; fb < NFB; ++fb) acc.a[fb][i] += xt[off + 32 * fb];
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+              for (int fb = 0; fb < NFB; ++fb) acc.a[fb][4 * g + j] += pg[j * L + 32 * fb];
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const float* const pr = xt + static_cast<unsigned>(min(8 * (i >> 2) + (i & 3) + h4, rlim) * L + n);
+#pragma unroll
+            for (int fb = 0; fb < NFB; ++fb) acc.a[fb][i] += pr[32 * fb];
+          }
         }
       }
       if (a.layer_norm == AMBER_MODE_INNER && !DBG(4096)) tile_layernorm_acc<L>(acc, a.gamma, a.beta, a.eps, nq);
@@ -985,19 +1017,14 @@ __global__ __launch_bounds__(64 * node_waves<L>()) void node_kernel_f2(const Nod
     auto store_tile = [&](float* out, const Tile<L>& t) {
       float* const ot = out + n0 * L;
       AMBER_REPIN_H4;
-      if (nstore == kTile) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const unsigned off = static_cast<unsigned>(hq + (8 * (i >> 2) + (i & 3)) * L);
+      for (int g = 0; g < 4; ++g) {
+        float* const pg = ot + static_cast<unsigned>(hq) + 8 * g * L;
 #pragma unroll
-          for (int fb = 0; fb < NFB; ++fb) ot[off + 32 * fb] = t.a[fb][i];
-        }
-      } else {
+        for (int j = 0; j < 4; ++j) {
+          if (nstore == kTile || 8 * g + j + h4 < nstore) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          if (8 * (i >> 2) + (i & 3) + h4 < nstore) {
-#pragma unroll
-            for (int fb = 0; fb < NFB; ++fb) ot[static_cast<unsigned>(hq + (8 * (i >> 2) + (i & 3)) * L) + 32 * fb] = t.a[fb][i];
+            for (int fb = 0; fb < NFB; ++fb) pg[j * L + 32 * fb] = t.a[fb][4 * g + j];
           }
         }
       }
@@ -1021,11 +1048,22 @@ __global__ __launch_bounds__(64 * node_waves<L>()) void node_kernel_f2(const Nod
         if constexpr (L > 64 || AMBER_NODE_RELOAD_V) {
           const float* const vt = (a.do_update ? a.x_out : a.x_in) + n0 * L;
           AMBER_REPIN_H4;
+          if (nvalid == kTile) {
 #pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const unsigned off = static_cast<unsigned>(min(8 * (i >> 2) + (i & 3) + h4, rlim) * L + nq);
+            for (int g = 0; g < 4; ++g) {
+              const float* const pg = vt + static_cast<unsigned>(hq) + 8 * g * L;
 #pragma unroll
-            for (int fb = 0; fb < NFB; ++fb) v.a[fb][i] = vt[off + 32 * fb];
+              for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int fb = 0; fb < NFB; ++fb) v.a[fb][4 * g + j] = pg[j * L + 32 * fb];
+            }
+          } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+              const float* const pr = vt + static_cast<unsigned>(min(8 * (i >> 2) + (i & 3) + h4, rlim) * L + nq);
+#pragma unroll
+              for (int fb = 0; fb < NFB; ++fb) v.a[fb][i] = pr[32 * fb];
+            }
           }
         }
         Tile<L> acc;
