@@ -873,9 +873,10 @@ int amber_mpn_pack_weights(const AmberMpnDesc* desc, const float* params, float*
     q32.n = 0;
     return e;
   };
-  auto pack_one = [&](int fmt, const float* W, int ld, int col0, int scol0, int scols, float* out) -> hipError_t {
+  // kperm: the matrix is applied to a tile held in accumulator registers (hidden layers, projections of x', decoder)
+  auto pack_one = [&](int fmt, const float* W, int ld, int col0, int scol0, int scols, int kperm, float* out) -> hipError_t {
     if (fmt == FMT_F2) {
-      q2.job[q2.n++] = F2PackJob{W, out, ld, col0, scol0, scols};
+      q2.job[q2.n++] = F2PackJob{W, out, ld, col0, scol0, scols, kperm};
       if (q2.n == kF2PackMaxJobs) return flush();
     } else {
       q32.job[q32.n++] = PackJob{W, out, ld, col0, 0};
@@ -884,18 +885,18 @@ int amber_mpn_pack_weights(const AmberMpnDesc* desc, const float* params, float*
     return hipSuccess;
   };
   auto pack_mlp = [&](const MlpLayout& m, int blocks0, int f00 = FMT_F32, int f01 = FMT_F32, int f02 = FMT_F32, bool share0 = false,
-                      int frest = FMT_F32) -> hipError_t {
+                      int frest = FMT_F32, int kperm0 = 0) -> hipError_t {  // kperm0: bit cb = column block cb of layer 0
     const int f0[3] = {f00, f01, f02};
     for (int l = 0; l < m.layers; ++l) {
       if (l == 0) {
         for (int cb = 0; cb < blocks0; ++cb)
           if (m.PW[0][cb] >= 0) {
             hipError_t e = pack_one(f0[cb], params + m.W[0], m.in_cols, cb * L, share0 ? 0 : cb * L, share0 ? blocks0 * L : L,
-                                    packed + m.PW[0][cb]);
+                                    (kperm0 >> cb) & 1, packed + m.PW[0][cb]);
             if (e != hipSuccess) return e;
           }
       } else if (m.PW[l][0] >= 0) {
-        hipError_t e = pack_one(frest, params + m.W[l], L, 0, 0, L, packed + m.PW[l][0]);
+        hipError_t e = pack_one(frest, params + m.W[l], L, 0, 0, L, 1, packed + m.PW[l][0]);
         if (e != hipSuccess) return e;
       }
     }
@@ -905,14 +906,15 @@ int amber_mpn_pack_weights(const AmberMpnDesc* desc, const float* params, float*
   HIP_TRY(pack_mlp(lay.edge_embed, 0), "pack edge embedding");
   for (int st = 0; st < desc->num_steps; ++st) {
     const int fe = use_fast_edge(*desc) ? FMT_F2 : FMT_F32, fn = use_fast_node(*desc) ? FMT_F2 : FMT_F32;
-    HIP_TRY(pack_mlp(lay.edge[st], 3, fn, fn, fe, false, fe), "pack edge MLP");
+    // W0s / W0d are applied by the node kernel to x' in accumulator registers, W0e by the edge kernel to rows of e
+    HIP_TRY(pack_mlp(lay.edge[st], 3, fn, fn, fe, false, fe, 0b011), "pack edge MLP");
     HIP_TRY(pack_mlp(lay.node[st], 2, fn, fn, FMT_F32, true, fn), "pack node MLP");
   }
   if (desc->has_head) {
     HIP_TRY(pack_mlp(lay.dec, 1), "pack decoder");
     for (int l = 0; l < desc->decoder_layers; ++l)
       if (lay.dec_f2[l] >= 0)
-        HIP_TRY(pack_one(FMT_F2, params + lay.dec.W[l], L, 0, 0, L, packed + lay.dec_f2[l]), "pack decoder (split precision)");
+        HIP_TRY(pack_one(FMT_F2, params + lay.dec.W[l], L, 0, 0, L, 1, packed + lay.dec_f2[l]), "pack decoder (split precision)");
   }
   HIP_TRY(flush(), "pack weights");
   return AMBER_OK;

@@ -37,6 +37,22 @@
 #define DBG(bit) 0
 #endif
 
+// In-kernel cycle stamps of the edge kernel's tile loop (diagnostic build only: make EXTRA=-DAMBER_STAMPS; the stamps go
+// to a buffer of their own that nothing else reads, and launch_edge_f2 prints the per-section averages).
+#ifdef AMBER_STAMPS
+#define STAMP(k)                                                    \
+  do {                                                              \
+    __builtin_amdgcn_sched_barrier(0);                              \
+    const unsigned long long _t = __builtin_amdgcn_s_memtime();     \
+    st_acc[k] += static_cast<unsigned>(_t - st_prev);               \
+    st_prev = _t;                                                   \
+    __builtin_amdgcn_sched_barrier(0);                              \
+  } while (0)
+constexpr int kStamps = 12;
+#else
+#define STAMP(k)
+#endif
+
 #ifndef AMBER_NODE_RELOAD_V
 #define AMBER_NODE_RELOAD_V 0
 #endif
@@ -191,9 +207,59 @@ DEVINL half4 lds_read_tr(const unsigned char* p) {
   return __builtin_bit_cast(half4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p)));
 }
 
-// consecutive rows of L floats whose byte offsets (plus a feature block's) fit the 12-bit immediate of a global access
+// consecutive rows of L floats whose byte offsets fit the 12-bit immediate of a global access
 template <int L>
 constexpr int kRowGroup = L >= 128 ? 8 : 16;
+
+// Which feature an accumulator column is.  The MFMA puts output column (fb, n) - feature block fb, lane n of a half - in
+// register fb of lane n; WHICH feature that column computes is the packer's choice (the column order of the B operand).
+// Column (fb, n) = feature NFB n + fb: a lane's NFB registers of one row are then NFB CONSECUTIVE floats of the row in
+// memory, so every direct row access (gathered P_s / P_d rows, residual rows, stores of e' / x' / P_s / P_d, partial
+// sums) is one 16-byte (L = 128) access a lane instead of four 4-byte ones: a quarter of the vector-memory instructions,
+// whose issue - not the bytes - was what the row phases of the tile loop waited for.  A contraction whose INPUT comes
+// from accumulator registers sees its k index permuted the same way (pack_f2: kperm).
+template <int L>
+DEVINL constexpr int fcol(int fb, int n) {
+  return (L / 32) * n + fb;
+}
+// the NFB consecutive floats at p (16 / 8 / 4 bytes), as one access
+template <int L>
+DEVINL void piece_load(const float* __restrict__ p, float (&v)[L / 32]) {
+  if constexpr (L == 128) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(p);
+    v[0] = t[0], v[1] = t[1], v[2] = t[2], v[3] = t[3];
+  } else if constexpr (L == 64) {
+    const f32x2 t = *reinterpret_cast<const f32x2*>(p);
+    v[0] = t[0], v[1] = t[1];
+  } else {
+    v[0] = p[0];
+  }
+}
+template <int L>
+DEVINL void piece_store(float* __restrict__ p, const float (&v)[L / 32]) {
+  if constexpr (L == 128) {
+    f32x4 t;
+    t[0] = v[0], t[1] = v[1], t[2] = v[2], t[3] = v[3];
+    *reinterpret_cast<f32x4*>(p) = t;
+  } else if constexpr (L == 64) {
+    f32x2 t;
+    t[0] = v[0], t[1] = v[1];
+    *reinterpret_cast<f32x2*>(p) = t;
+  } else {
+    p[0] = v[0];
+  }
+}
+// register fb of row register i of a tile <- / -> piece
+template <int L>
+DEVINL void tile_set_piece(Tile<L>& t, int i, const float (&v)[L / 32]) {
+#pragma unroll
+  for (int fb = 0; fb < L / 32; ++fb) t.a[fb][i] = v[fb];
+}
+template <int L>
+DEVINL void tile_get_piece(const Tile<L>& t, int i, float (&v)[L / 32]) {
+#pragma unroll
+  for (int fb = 0; fb < L / 32; ++fb) v[fb] = t.a[fb][i];
+}
 
 // streamed rows of the e tile as whole row pieces: v[pass][it] = e[row it*8 + lane/8][32 pass + 4 (lane % 8) .. +3]
 template <int L>
@@ -377,11 +443,8 @@ template <int L>
 DEVINL void tile_layernorm_acc(Tile<L>& acc, const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int n) {
   constexpr int NFB = L / 32;
   float g[NFB], bt[NFB];
-#pragma unroll
-  for (int fb = 0; fb < NFB; ++fb) {
-    g[fb] = gamma[32 * fb + n];
-    bt[fb] = beta[32 * fb + n];
-  }
+  piece_load<L>(gamma + NFB * n, g);
+  piece_load<L>(beta + NFB * n, bt);
   float s[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
@@ -411,6 +474,9 @@ DEVINL void tile_layernorm_acc(Tile<L>& acc, const float* __restrict__ gamma, co
   }
 }
 
+#ifdef AMBER_STAMPS
+__device__ unsigned long long g_stamps[kStamps + 1];
+#endif
 // EMB: first step with the linear edge embedding fused in (e is computed on the fly instead of read)
 template <int L, bool EMB, bool SPLIT>
 __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const EdgeArgs a, const int64_t ntiles) {
@@ -492,17 +558,26 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
     }
   };
   auto gather_ps = [&](int sidx, int nq) {
-    const float* const psn = a.Ps + nq;
+    const float* const psn = a.Ps + NFB * nq;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const unsigned si = static_cast<unsigned>(row_bcast(sidx, i));
-      const float* ps = psn + static_cast<size_t>(DBG(32) ? 0u : si) * L;
-#pragma unroll
-      for (int fb = 0; fb < NFB; ++fb) pn.a[fb][i] = ps[32 * fb];
+      float pc[NFB];
+      piece_load<L>(psn + static_cast<size_t>(DBG(32) ? 0u : si) * L, pc);
+      tile_set_piece<L>(pn, i, pc);
     }
   };
   if (PIPE && tile < t_end) load_e(tile);
+#ifdef AMBER_STAMPS
+  unsigned st_acc[kStamps] = {};
+  unsigned st_tiles = 0;
+  unsigned long long st_prev = __builtin_amdgcn_s_memtime();
+#endif
   for (; tile < t_end; tile += stride) {
+    STAMP(0);
+#ifdef AMBER_STAMPS
+    ++st_tiles;
+#endif
     const int64_t p0 = tile * kTile;
     const int nvalid = (a.E - p0) < kTile ? static_cast<int>(a.E - p0) : kTile;  // >= 1: tile < ntiles
     float* const et = a.e + p0 * L;     // this tile's rows of e (wave-uniform base, 32-bit lane offsets)
@@ -510,7 +585,7 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
     const int rlim = nvalid - 1;
     // Lane offsets of the direct row accesses are recomputed per tile from these opaque copies: hoisted out of the tile
     // loop they would occupy dozens of registers for its whole length.
-    int hq = 16 * h * L + n, nq = n;  // first row of this lane's half, its feature column
+    int hq = 16 * h * L + NFB * n, nq = n;  // first row of this lane's half at its NFB features; its lane of the half
     asm volatile("" : "+v"(hq), "+v"(nq));
     // ---- first step with the edge embedding fused in: the rows of e are computed, not read (K1: Embedding.forward,
     // src/mpn/common/embedding.py:44-54, linear form) - directly in accumulator layout ----
@@ -527,9 +602,9 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
       float wq[NFB][kMaxFusedEmbed], bq[NFB];
 #pragma unroll
       for (int fb = 0; fb < NFB; ++fb) {
-        bq[fb] = a.emb_b[32 * fb + nq];
+        bq[fb] = a.emb_b[fcol<L>(fb, nq)];
 #pragma unroll
-        for (int k = 0; k < kMaxFusedEmbed; ++k) wq[fb][k] = k < a.emb_f ? a.emb_w[(32 * fb + nq) * a.emb_f + k] : 0.f;
+        for (int k = 0; k < kMaxFusedEmbed; ++k) wq[fb][k] = k < a.emb_f ? a.emb_w[fcol<L>(fb, nq) * a.emb_f + k] : 0.f;
       }
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
@@ -551,9 +626,9 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
       float wq[NFB][kMaxFusedEmbed], bq[NFB];
 #pragma unroll
       for (int fb = 0; fb < NFB; ++fb) {
-        bq[fb] = fold[kMaxFusedEmbed * L + 32 * fb + nq];
+        bq[fb] = fold[kMaxFusedEmbed * L + fcol<L>(fb, nq)];
 #pragma unroll
-        for (int k = 0; k < kMaxFusedEmbed; ++k) wq[fb][k] = fold[k * L + 32 * fb + nq];
+        for (int k = 0; k < kMaxFusedEmbed; ++k) wq[fb][k] = fold[k * L + fcol<L>(fb, nq)];
       }
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
@@ -589,6 +664,7 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
     const int dprev = __shfl_up(d0, 1);  // every lane takes part: the shuffle must not sit behind the n > 0 test
     unsigned newseg = static_cast<unsigned>(__ballot((d0 != dprev) & (n > 0)));
     if (nvalid < kTile) newseg &= (1u << nvalid) - 1u;
+    STAMP(1);  // loads issued, bookkeeping
 
     // ---- layer 0: acc = (P_s + P_d) + W0e e, in the scaled domain ----
     float scale = 1.f, inv = 1.f, us = 1.f;
@@ -596,23 +672,28 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
       fold_tile_add(acc);  // exact fp32, no scaled domain
     } else {
       pow2_scale(wave_max(landing_absmax<L>(la)), scale, inv);
+      STAMP(2);  // e rows arrived, tile maximum
       tile_scale<L>(acc, scale * wscale0);
+      STAMP(3);  // P_s rows arrived
       if (!DBG(8)) gemm_rows<L, SPLIT>(acc, la, scale, win, wo, smem, lane);
       us = inv * wsinv0;
     }
+    STAMP(4);  // layer 0 contraction
     // destination terms (rows repeat inside a tile: L1 / L2 hits) join after the contraction, when the landing
     // registers of e are free again
     {
-      const float* const pdn = a.Pd + nq;
+      const float* const pdn = a.Pd + NFB * nq;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const unsigned di = static_cast<unsigned>(row_bcast(dx0, i));
-        const float* pd = pdn + static_cast<size_t>(DBG(2) ? 0u : di) * L;
+        float pc[NFB];
+        piece_load<L>(pdn + static_cast<size_t>(DBG(2) ? 0u : di) * L, pc);
 #pragma unroll
-        for (int fb = 0; fb < NFB; ++fb) acc.a[fb][i] = fmaf(acc.a[fb][i], us, pd[32 * fb]);
+        for (int fb = 0; fb < NFB; ++fb) acc.a[fb][i] = fmaf(acc.a[fb][i], us, pc[fb]);
       }
     }
     tile_act_fast<L>(acc, a.act);
+    STAMP(5);  // P_d rows, activation
     // ---- hidden layers: the activations go through the window as a [feature][edge] image ----
 #pragma unroll 1
     for (int l = 1; l < a.nl; ++l) {
@@ -625,16 +706,18 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
       if (!DBG(8)) gemm_acc<L, SPLIT>(nxt, acc, scale, win, wo, smem + l * MAT_BYTES, lane);
       {
         const float post = inv * wg[L * L];
+        float bv[NFB];
+        piece_load<L>(a.layers[l].b + NFB * n, bv);
 #pragma unroll
         for (int fb = 0; fb < NFB; ++fb) {
-          const float b = a.layers[l].b[32 * fb + n];
 #pragma unroll
-          for (int i = 0; i < 16; ++i) nxt.a[fb][i] = fmaf(nxt.a[fb][i], post, b);
+          for (int i = 0; i < 16; ++i) nxt.a[fb][i] = fmaf(nxt.a[fb][i], post, bv[fb]);
         }
       }
       tile_act_fast<L>(nxt, a.act);
       acc = nxt;
     }
+    STAMP(6);  // hidden layers
     // ---- residual: the rows of e again (this wave's own loads of a moment ago), now feature per lane ----
     if (EMB && a.residual == AMBER_MODE_INNER) {
       Tile<L> e0;
@@ -647,17 +730,21 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
         for (int g = 0; g < 16 / kRowGroup<L>; ++g) {
           const float* const pg = et + static_cast<unsigned>(hq) + kRowGroup<L> * g * L;
 #pragma unroll
-          for (int j = 0; j < kRowGroup<L>; ++j)
+          for (int j = 0; j < kRowGroup<L>; ++j) {
+            float pc[NFB];
+            piece_load<L>(pg + j * L, pc);
 #pragma unroll
-            for (int fb = 0; fb < NFB; ++fb) acc.a[fb][kRowGroup<L> * g + j] += pg[j * L + 32 * fb];
+            for (int fb = 0; fb < NFB; ++fb) acc.a[fb][kRowGroup<L> * g + j] += pc[fb];
+          }
         }
       } else {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           // rows beyond the end repeat the last edge
-          const float* const pr = et + static_cast<unsigned>(min(i + 16 * h, rlim) * L + n);
+          float pc[NFB];
+          piece_load<L>(et + static_cast<unsigned>(min(i + 16 * h, rlim) * L + NFB * n), pc);
 #pragma unroll
-          for (int fb = 0; fb < NFB; ++fb) acc.a[fb][i] += pr[32 * fb];
+          for (int fb = 0; fb < NFB; ++fb) acc.a[fb][i] += pc[fb];
         }
       }
     }
@@ -666,8 +753,10 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
       if (tile + stride < t_end) load_e(tile + stride);
       __builtin_amdgcn_sched_barrier(0);
     }
+    STAMP(7);  // residual
     // ---- LayerNorm over the features of every edge: across the lanes of a half, one register per edge ----
     if (a.layer_norm == AMBER_MODE_INNER && !DBG(64)) tile_layernorm_acc<L>(acc, a.gamma, a.beta, a.eps, n);
+    STAMP(8);  // LayerNorm
     // ---- stores of e' (two whole 128-byte row pieces per register) ----
     if (a.write_e || a.out_edge) {
       int pm = 0;
@@ -683,8 +772,9 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
 #pragma unroll
           for (int j = 0; j < kRowGroup<L>; ++j) {
             if (nvalid == kTile || kRowGroup<L> * g + j + 16 * h < nvalid) {
-#pragma unroll
-              for (int fb = 0; fb < NFB; ++fb) pg[j * L + 32 * fb] = acc.a[fb][kRowGroup<L> * g + j];
+              float pc[NFB];
+              tile_get_piece<L>(acc, kRowGroup<L> * g + j, pc);
+              piece_store<L>(pg + j * L, pc);
             }
           }
         }
@@ -695,13 +785,14 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
           const int r = i + 16 * h;
           const unsigned orow = static_cast<unsigned>(row_bcast(pm, i));
           if (r < nvalid) {
-            float* po = a.out_edge + static_cast<size_t>(orow) * L + n;
-#pragma unroll
-            for (int fb = 0; fb < NFB; ++fb) po[32 * fb] = acc.a[fb][i];
+            float pc[NFB];
+            tile_get_piece<L>(acc, i, pc);
+            piece_store<L>(a.out_edge + static_cast<size_t>(orow) * L + NFB * n, pc);
           }
         }
       }
     }
+    STAMP(9);  // stores of e'
     // ---- per-destination sums in CSR order: every lane adds up its own registers (its half's sixteen consecutive
     // edges); a row that ends inside the half goes to agg, rows cut by the half's borders to head / tail of the
     // reduction tile 2 tile + h (see mpn_kernels.hip); the two halves differ only in WHERE their rows end, which the
@@ -721,9 +812,9 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
         bool sb = q0 > static_cast<int64_t>(rp_first);  // the half's first row began before it
         const unsigned mybits = h ? (newseg >> 16) : (newseg & 0xffffu);
         const unsigned anybits = (newseg | (newseg >> 16)) & 0xfffeu;  // wave-uniform: some half ends a row before position i
-        float* const slot_head = a.head + (2 * tile + h) * L + nq;
-        float* const slot_tail = a.tail + (2 * tile + h) * L + nq;
-        float* const aggn = a.agg + nq;
+        float* const slot_head = a.head + (2 * tile + h) * L + NFB * nq;
+        float* const slot_tail = a.tail + (2 * tile + h) * L + NFB * nq;
+        float* const aggn = a.agg + NFB * nq;
         float sum[NFB];
 #pragma unroll
         for (int fb = 0; fb < NFB; ++fb) sum[fb] = 0.f;
@@ -732,12 +823,9 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
           if (i > 0 && ((anybits >> i) & 1u)) {
             const unsigned dp = static_cast<unsigned>(row_bcast(dx0, i - 1));  // outside the predicated part: all lanes take part
             if ((mybits >> i) & 1u) {
-              float* const dstp = sb ? slot_head : aggn + static_cast<size_t>(dp) * L;
+              piece_store<L>(sb ? slot_head : aggn + static_cast<size_t>(dp) * L, sum);
 #pragma unroll
-              for (int fb = 0; fb < NFB; ++fb) {
-                dstp[32 * fb] = sum[fb];
-                sum[fb] = 0.f;
-              }
+              for (int fb = 0; fb < NFB; ++fb) sum[fb] = 0.f;
               sb = false;
             }
           }
@@ -746,15 +834,21 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
         }
         if (nvh > 0) {
           float* const dstp = (!sb && ends_last) ? aggn + static_cast<size_t>(static_cast<unsigned>(lastd)) * L : (sb ? slot_head : slot_tail);
-#pragma unroll
-          for (int fb = 0; fb < NFB; ++fb) dstp[32 * fb] = sum[fb];
+          piece_store<L>(dstp, sum);
         }
       }
     }
     sx0 = sx1;
     d0 = d1;
     dx0 = dx1;
+    STAMP(10);  // per-destination sums
   }
+#ifdef AMBER_STAMPS
+  if (lane == 0) {
+    for (int k = 0; k < kStamps; ++k) atomicAdd(&g_stamps[k], static_cast<unsigned long long>(st_acc[k]));
+    atomicAdd(&g_stamps[kStamps], static_cast<unsigned long long>(st_tiles));
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -857,7 +951,7 @@ __global__ __launch_bounds__(64 * node_waves<L>()) void node_kernel_f2(const Nod
     const float* const xt = a.x_in + n0 * L;
     // (h4: the row numbers 8 (i >> 2) + (i & 3) + 4 h of the 16 registers are cheaper to recompute than to keep -
     // hoisted out of the loop they are spilled, and every scratch reload drains the in-order memory counter)
-    int hq = 4 * h * L + n, nq = n, lq = lane, h4 = 4 * h;
+    int hq = 4 * h * L + NFB * n, nq = n, lq = lane, h4 = 4 * h;  // hq: first row of the half at this lane's NFB features
     asm volatile("" : "+v"(hq), "+v"(nq), "+v"(lq), "+v"(h4));
     // the sixteen row numbers are formed again in every phase that uses them (one add each, partial tiles only): shared
     // between the phases they stay live across the contractions and are spilled inside the tile loop
@@ -952,11 +1046,12 @@ __global__ __launch_bounds__(64 * node_waves<L>()) void node_kernel_f2(const Nod
         if (!DBG(256)) gemm_rows<L, SPLIT, true>(acc, lg, sg, win, wo, wl, lane);
         {
           const float post = ig * a.w0x[L * L];
+          float bv[NFB];
+          piece_load<L>(a.b0 + NFB * nq, bv);
 #pragma unroll
           for (int fb = 0; fb < NFB; ++fb) {
-            const float bv = a.b0[32 * fb + nq];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc.a[fb][i] = fmaf(acc.a[fb][i], post, bv);
+            for (int i = 0; i < 16; ++i) acc.a[fb][i] = fmaf(acc.a[fb][i], post, bv[fb]);
           }
         }
         tile_act_fast<L>(acc, a.act);
@@ -971,11 +1066,12 @@ __global__ __launch_bounds__(64 * node_waves<L>()) void node_kernel_f2(const Nod
         if (!DBG(256)) gemm_acc<L, SPLIT, true>(nxt, acc, scale, win, wo, wl, lane);
         {
           const float post = inv * wg[L * L];
+          float bv[NFB];
+          piece_load<L>(a.layers[l].b + NFB * nq, bv);
 #pragma unroll
           for (int fb = 0; fb < NFB; ++fb) {
-            const float bv = a.layers[l].b[32 * fb + nq];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) nxt.a[fb][i] = fmaf(nxt.a[fb][i], post, bv);
+            for (int i = 0; i < 16; ++i) nxt.a[fb][i] = fmaf(nxt.a[fb][i], post, bv[fb]);
           }
         }
         tile_act_fast<L>(nxt, a.act);
@@ -990,16 +1086,20 @@ __global__ __launch_bounds__(64 * node_waves<L>()) void node_kernel_f2(const Nod
           for (int g = 0; g < 4; ++g) {
             const float* const pg = xt + static_cast<unsigned>(hq) + 8 * g * L;
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 4; ++j) {
+              float pc[NFB];
+              piece_load<L>(pg + j * L, pc);
 #pragma unroll
-              for (int fb = 0; fb < NFB; ++fb) acc.a[fb][4 * g + j] += pg[j * L + 32 * fb];
+              for (int fb = 0; fb < NFB; ++fb) acc.a[fb][4 * g + j] += pc[fb];
+            }
           }
         } else {
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
-            const float* const pr = xt + static_cast<unsigned>(min(8 * (i >> 2) + (i & 3) + h4, rlim) * L + n);
+            float pc[NFB];
+            piece_load<L>(xt + static_cast<unsigned>(min(8 * (i >> 2) + (i & 3) + h4, rlim) * L + NFB * n), pc);
 #pragma unroll
-            for (int fb = 0; fb < NFB; ++fb) acc.a[fb][i] += pr[32 * fb];
+            for (int fb = 0; fb < NFB; ++fb) acc.a[fb][i] += pc[fb];
           }
         }
       }
@@ -1008,9 +1108,9 @@ __global__ __launch_bounds__(64 * node_waves<L>()) void node_kernel_f2(const Nod
     } else {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const unsigned off = static_cast<unsigned>(min(8 * (i >> 2) + (i & 3) + h4, rlim) * L + n);
-#pragma unroll
-        for (int fb = 0; fb < NFB; ++fb) v.a[fb][i] = xt[off + 32 * fb];
+        float pc[NFB];
+        piece_load<L>(xt + static_cast<unsigned>(min(8 * (i >> 2) + (i & 3) + h4, rlim) * L + NFB * n), pc);
+        tile_set_piece<L>(v, i, pc);
       }
     }
     // store a tile in accumulator layout as rows n0 .. n0 + nvalid - 1 of `out`
@@ -1023,8 +1123,9 @@ __global__ __launch_bounds__(64 * node_waves<L>()) void node_kernel_f2(const Nod
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           if (nstore == kTile || 8 * g + j + h4 < nstore) {
-#pragma unroll
-            for (int fb = 0; fb < NFB; ++fb) pg[j * L + 32 * fb] = t.a[fb][4 * g + j];
+            float pc[NFB];
+            tile_get_piece<L>(t, 4 * g + j, pc);
+            piece_store<L>(pg + j * L, pc);
           }
         }
       }
@@ -1053,16 +1154,18 @@ __global__ __launch_bounds__(64 * node_waves<L>()) void node_kernel_f2(const Nod
             for (int g = 0; g < 4; ++g) {
               const float* const pg = vt + static_cast<unsigned>(hq) + 8 * g * L;
 #pragma unroll
-              for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int fb = 0; fb < NFB; ++fb) v.a[fb][4 * g + j] = pg[j * L + 32 * fb];
+              for (int j = 0; j < 4; ++j) {
+                float pc[NFB];
+                piece_load<L>(pg + j * L, pc);
+                tile_set_piece<L>(v, 4 * g + j, pc);
+              }
             }
           } else {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-              const float* const pr = vt + static_cast<unsigned>(min(8 * (i >> 2) + (i & 3) + h4, rlim) * L + nq);
-#pragma unroll
-              for (int fb = 0; fb < NFB; ++fb) v.a[fb][i] = pr[32 * fb];
+              float pc[NFB];
+              piece_load<L>(vt + static_cast<unsigned>(min(8 * (i >> 2) + (i & 3) + h4, rlim) * L + NFB * nq), pc);
+              tile_set_piece<L>(v, i, pc);
             }
           }
         }
@@ -1071,11 +1174,12 @@ __global__ __launch_bounds__(64 * node_waves<L>()) void node_kernel_f2(const Nod
         if (!DBG(256)) gemm_acc<L, SPLIT, true>(acc, v, scale, win, wo, wl, lane);
         {
           const float post = inv * a.w0d[L * L];
+          float bv[NFB];
+          piece_load<L>(a.b0e + NFB * nq, bv);
 #pragma unroll
           for (int fb = 0; fb < NFB; ++fb) {
-            const float bv = a.b0e[32 * fb + nq];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc.a[fb][i] = fmaf(acc.a[fb][i], post, bv);
+            for (int i = 0; i < 16; ++i) acc.a[fb][i] = fmaf(acc.a[fb][i], post, bv[fb]);
           }
         }
         store_tile(a.Pd, acc);
@@ -1095,11 +1199,12 @@ __global__ __launch_bounds__(64 * node_waves<L>()) void node_kernel_f2(const Nod
       gemm_acc<L, SPLIT, true>(nxt, v, scale, win, wo, wl, lane);
       {
         const float post = inv * wg[L * L];
+        float bv[NFB];
+        piece_load<L>(a.dense[l].b + NFB * nq, bv);
 #pragma unroll
         for (int fb = 0; fb < NFB; ++fb) {
-          const float bv = a.dense[l].b[32 * fb + nq];
 #pragma unroll
-          for (int i = 0; i < 16; ++i) nxt.a[fb][i] = fmaf(nxt.a[fb][i], post, bv);
+          for (int i = 0; i < 16; ++i) nxt.a[fb][i] = fmaf(nxt.a[fb][i], post, bv[fb]);
         }
       }
       tile_act_fast<L>(nxt, a.dense_act);
@@ -1108,8 +1213,7 @@ __global__ __launch_bounds__(64 * node_waves<L>()) void node_kernel_f2(const Nod
     if (a.do_readout) {
       // readout Linear(L, 1): a dot product over the features = over the lanes of a half, one register per row
       float wq[NFB];
-#pragma unroll
-      for (int fb = 0; fb < NFB; ++fb) wq[fb] = a.wr[32 * fb + nq];
+      piece_load<L>(a.wr + NFB * nq, wq);
       const float br = a.br[0];
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
@@ -1132,7 +1236,10 @@ __global__ __launch_bounds__(64 * node_waves<L>()) void node_kernel_f2(const Nod
 // ---------------------------------------------------------------------------------------------------
 // weight packing: absmax -> power-of-two scale -> hi/lo fp16 in B-operand order (+ header)
 // ---------------------------------------------------------------------------------------------------
-// out: [s][fb][hi|lo][lane][8 halves]; element j of lane (h, r) is W[32 fb + r][col0 + 16 s + 8 h + j];
+// out: [s][fb][hi|lo][lane][8 halves]; element j of lane (h, r) is W[fcol(fb, r)][col0 + k], the output feature of
+// accumulator column (fb, r) (see fcol), with k = 16 s + 8 h + j when the contraction's input comes from memory rows in
+// their own order (kperm = 0) and k = fcol(s / 2, 16 (s % 2) + 8 h + j) when it comes from accumulator registers through
+// the window ([feature][row] image of pass s / 2: image row 16 (s % 2) + 8 h + j is accumulator column (s / 2, that row));
 // header (8 floats after the L*L*4 body bytes): [0] = inverse scale, [1] = scale
 // Batched form (one launch pair for many matrices; a training step re-tiles every matrix after each optimizer step):
 // a workgroup per job finds max|W| over the job's scale columns (max is order-independent: no atomics needed),
@@ -1168,11 +1275,13 @@ __global__ void pack_f2_batch_kernel(const F2PackBatch jobs) {
   }
   if (i >= NS * NFB * 64) return;
   const int lane = i & 63, fb = (i >> 6) % NFB, s = (i >> 6) / NFB;
-  const float* src = jb.W + static_cast<int64_t>(32 * fb + (lane & 31)) * jb.ld + jb.col0 + 16 * s + 8 * (lane >> 5);
+  const float* src = jb.W + static_cast<int64_t>(fcol<L>(fb, lane & 31)) * jb.ld + jb.col0;
   half8 hi, lo;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    const float ws = src[j] * scale;
+    const int kk = 8 * (lane >> 5) + j;
+    const int k = jb.kperm ? fcol<L>(s >> 1, 16 * (s & 1) + kk) : 16 * s + kk;
+    const float ws = src[k] * scale;
     const _Float16 hh = static_cast<_Float16>(ws);
     hi[j] = hh;
     lo[j] = static_cast<_Float16>(ws - static_cast<float>(hh));
@@ -1198,10 +1307,10 @@ hipError_t launch_pack_f2_batch(int L, const F2PackBatch& b, hipStream_t s) {
     default: return hipErrorInvalidValue;
   }
 }
-hipError_t launch_pack_f2(int L, const float* W, int ld, int col0, int scale_col0, int scale_cols, float* out, hipStream_t s) {
+hipError_t launch_pack_f2(int L, const float* W, int ld, int col0, int scale_col0, int scale_cols, int kperm, float* out, hipStream_t s) {
   F2PackBatch b{};
   b.n = 1;
-  b.job[0] = F2PackJob{W, out, ld, col0, scale_col0, scale_cols};
+  b.job[0] = F2PackJob{W, out, ld, col0, scale_col0, scale_cols, kperm};
   return launch_pack_f2_batch(L, b, s);
 }
 
@@ -1225,7 +1334,24 @@ static hipError_t launch_edge_f2_t(const EdgeArgs& a, int num_cus, hipStream_t s
   if (e != hipSuccess) return e;
   int64_t grid = (num_cus / 8) * 8;  // one persistent workgroup per CU, a multiple of the 8 XCDs
   if (grid < 8) grid = 8;
+#ifdef AMBER_STAMPS
+  unsigned long long zero[kStamps + 1] = {};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), zero, sizeof(zero));
+#endif
   hipLaunchKernelGGL((edge_kernel_f2<L, EMB, SPLIT>), dim3(static_cast<unsigned>(grid)), dim3(64 * edge_waves<L>()), lds, s, a, ntiles);
+#ifdef AMBER_STAMPS
+  {
+    (void)hipStreamSynchronize(s);
+    unsigned long long got[kStamps + 1] = {};
+    (void)hipMemcpyFromSymbol(got, HIP_SYMBOL(g_stamps), sizeof(got));
+    static const char* names[kStamps] = {"loop-top", "issue-loads", "wait-e+max", "wait-Ps+scale", "gemm0", "Pd+act", "hidden", "residual", "LN", "stores", "segsum", ""};
+    double tot = 0;
+    for (int k = 0; k < kStamps; ++k) tot += static_cast<double>(got[k]);
+    fprintf(stderr, "[stamps L=%d EMB=%d] tiles %llu, cycles/tile %.0f:", L, int(EMB), got[kStamps], tot / static_cast<double>(got[kStamps] ? got[kStamps] : 1));
+    for (int k = 0; k < 11; ++k) fprintf(stderr, " %s %.0f", names[k], static_cast<double>(got[k]) / static_cast<double>(got[kStamps] ? got[kStamps] : 1));
+    fprintf(stderr, "\n");
+  }
+#endif
   return hipGetLastError();
 }
 template <int L>

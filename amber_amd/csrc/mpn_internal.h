@@ -140,13 +140,14 @@ struct F2PackJob {
   const float* W;   // [L, ld]
   float* out;       // packed matrix + header
   int32_t ld, col0, scale_col0, scale_cols;
+  int32_t kperm;    // 1: the contraction's input arrives from accumulator registers (k order permuted like the columns)
 };
 struct F2PackBatch {
   F2PackJob job[kF2PackMaxJobs];
   int32_t n;
 };
 hipError_t launch_pack_f2_batch(int L, const F2PackBatch& b, hipStream_t s);
-hipError_t launch_pack_f2(int L, const float* W, int ld, int col0, int scale_col0, int scale_cols, float* out, hipStream_t s);
+hipError_t launch_pack_f2(int L, const float* W, int ld, int col0, int scale_col0, int scale_cols, int kperm, float* out, hipStream_t s);
 hipError_t launch_edge_f2(int L, const EdgeArgs& a, int num_cus, hipStream_t s);
 bool edge_f2_supported(int L, int nl, int act, int residual, int layer_norm);
 // feature-per-lane node kernel (update + next-step projections; weights as B operand, W0x / W0a sharing one scale)
