@@ -646,6 +646,14 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
     };
     // ---- streamed e rows (whole row pieces; PIPE: issued during the previous tile's epilogue) and gathered
     // first-layer terms, straight into the accumulator layout ----
+    // (the output rows of the last step's edge latents: loaded HERE, ahead of the tile's other loads, so that the waits
+    // for those cover it; a load left pending at the stores makes the compiler drain the memory counter after them)
+    int pm = 0;
+    if (a.out_edge) {
+      int64_t p = p0 + xr;
+      if (p > a.E - 1) p = a.E - 1;
+      pm = a.perm[p];
+    }
     if constexpr (!EMB && !PIPE) load_e(tile);
     gather_ps(sx0, nq);
     Tile<L> acc = pn;
@@ -693,6 +701,13 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
       }
     }
     tile_act_fast<L>(acc, a.act);
+    // Where this half's first row began and its last row ends (rowptr words loaded at the top of the tile).  Taken here,
+    // where the in-order memory counter has just been waited down for the P_d rows anyway: read after the stores of e'
+    // they would make the wave wait until those stores have drained.
+    const int64_t q0 = p0 + 16 * h;
+    int sb_i = q0 > static_cast<int64_t>(rp_first) ? 1 : 0;          // the half's first row began before it
+    int ends_last_i = (q0 + nvh) == static_cast<int64_t>(rp_last) ? 1 : 0;  // its last row ends with it
+    asm volatile("" : "+v"(sb_i), "+v"(ends_last_i));  // evaluated HERE, not sunk to the point of use
     STAMP(5);  // P_d rows, activation
     // ---- hidden layers: the activations go through the window as a [feature][edge] image ----
 #pragma unroll 1
@@ -759,22 +774,25 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
     STAMP(8);  // LayerNorm
     // ---- stores of e' (two whole 128-byte row pieces per register) ----
     if (a.write_e || a.out_edge) {
-      int pm = 0;
-      if (a.out_edge) {
-        int64_t p = p0 + xr;
-        if (p > a.E - 1) p = a.E - 1;
-        pm = a.perm[p];
-      }
       if (a.write_e && !DBG(16)) {
+        if (nvalid == kTile) {
 #pragma unroll
-        for (int g = 0; g < 16 / kRowGroup<L>; ++g) {
-          float* const pg = eo + static_cast<unsigned>(hq) + kRowGroup<L> * g * L;  // one address per group, see the residual
+          for (int g = 0; g < 16 / kRowGroup<L>; ++g) {
+            float* const pg = eo + static_cast<unsigned>(hq) + kRowGroup<L> * g * L;  // one address per group, see the residual
 #pragma unroll
-          for (int j = 0; j < kRowGroup<L>; ++j) {
-            if (nvalid == kTile || kRowGroup<L> * g + j + 16 * h < nvalid) {
+            for (int j = 0; j < kRowGroup<L>; ++j) {
               float pc[NFB];
               tile_get_piece<L>(acc, kRowGroup<L> * g + j, pc);
               piece_store<L>(pg + j * L, pc);
+            }
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            if (i + 16 * h < nvalid) {
+              float pc[NFB];
+              tile_get_piece<L>(acc, i, pc);
+              piece_store<L>(eo + static_cast<unsigned>(hq) + i * L, pc);
             }
           }
         }
@@ -807,9 +825,8 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
           }
       }
       if (!DBG(4)) {
-        const int64_t q0 = p0 + 16 * h;
-        const bool ends_last = (q0 + nvh) == static_cast<int64_t>(rp_last);
-        bool sb = q0 > static_cast<int64_t>(rp_first);  // the half's first row began before it
+        bool sb = sb_i != 0;
+        const bool ends_last = ends_last_i != 0;
         const unsigned mybits = h ? (newseg >> 16) : (newseg & 0xffffu);
         const unsigned anybits = (newseg | (newseg >> 16)) & 0xfffeu;  // wave-uniform: some half ends a row before position i
         float* const slot_head = a.head + (2 * tile + h) * L + NFB * nq;
@@ -866,6 +883,9 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
 // ---------------------------------------------------------------------------------------------------
 // HEAD: the instantiation of the LAST node launch of a SupervisedMPN forward - no projections follow, the decoder's
 // layers and the readout do (kept apart so that neither variant pays the other's registers).
+#ifdef AMBER_STAMPS
+__device__ unsigned long long g_nstamps[kStamps + 1];
+#endif
 template <int L, bool SPLIT, bool HEAD>
 __global__ __launch_bounds__(64 * node_waves<L>()) void node_kernel_f2(const NodeArgs a, const int64_t ntiles, const int resident) {
   constexpr int NFB = L / 32;
@@ -939,7 +959,16 @@ __global__ __launch_bounds__(64 * node_waves<L>()) void node_kernel_f2(const Nod
     return smem + slot * MAT_BYTES;
   };
 
+#ifdef AMBER_STAMPS
+  unsigned st_acc[kStamps] = {};
+  unsigned st_tiles = 0;
+  unsigned long long st_prev = __builtin_amdgcn_s_memtime();
+#endif
   for (int64_t b = 0; b < nbatch; ++b) {
+    STAMP(0);
+#ifdef AMBER_STAMPS
+    ++st_tiles;
+#endif
     // A wave without a tile of its own keeps the workgroup's barriers: it recomputes the last tile of the range and
     // stores nothing (nstore = 0) - cheaper for the register allocator than guarding every phase.
     const int64_t mytile = first + b * stride + wave;
@@ -989,9 +1018,12 @@ __global__ __launch_bounds__(64 * node_waves<L>()) void node_kernel_f2(const Nod
           for (int ps = 0; ps < NFB; ++ps) lx.v[ps][it] = px[ps * 8];
         }
         pow2_scale(wave_max(landing_absmax<L>(lx)), scale, inv);
+        STAMP(1);  // x rows arrived
         tile_zero<L>(acc);  // the first MFMAs take the constant 0 as C; the bias joins the final rescale
         const unsigned char* wl = begin_phase(k++);
+        STAMP(2);  // barrier
         if (!DBG(256)) gemm_rows<L, SPLIT, true>(acc, lx, scale, win, wo, wl, lane);
+        STAMP(3);  // W0x
       }
       {
         // ---- whole row pieces of the aggregate: sums of the edge kernel -> mean ----
@@ -1042,8 +1074,11 @@ __global__ __launch_bounds__(64 * node_waves<L>()) void node_kernel_f2(const Nod
         float sg, ig;
         pow2_scale(wave_max(landing_absmax<L>(lg)), sg, ig);
         tile_scale<L>(acc, sg * inv);
+        STAMP(4);  // aggregate rows arrived, mean
         const unsigned char* wl = begin_phase(k++);
+        STAMP(2);
         if (!DBG(256)) gemm_rows<L, SPLIT, true>(acc, lg, sg, win, wo, wl, lane);
+        STAMP(5);  // W0a
         {
           const float post = ig * a.w0x[L * L];
           float bv[NFB];
@@ -1058,12 +1093,15 @@ __global__ __launch_bounds__(64 * node_waves<L>()) void node_kernel_f2(const Nod
       }
 #pragma unroll 1
       for (int l = 1; l < a.nl; ++l) {
+        STAMP(6);  // bias, activation
         const unsigned char* wl = begin_phase(k++);
+        STAMP(2);
         const float* wg = a.layers[l].w;
         pow2_scale(wave_max(tile_absmax<L>(acc)), scale, inv);
         Tile<L> nxt;
         tile_zero<L>(nxt);
         if (!DBG(256)) gemm_acc<L, SPLIT, true>(nxt, acc, scale, win, wo, wl, lane);
+        STAMP(7);  // hidden layer
         {
           const float post = inv * wg[L * L];
           float bv[NFB];
@@ -1117,25 +1155,43 @@ __global__ __launch_bounds__(64 * node_waves<L>()) void node_kernel_f2(const Nod
     auto store_tile = [&](float* out, const Tile<L>& t) {
       float* const ot = out + n0 * L;
       AMBER_REPIN_H4;
+      if (nstore == kTile) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        float* const pg = ot + static_cast<unsigned>(hq) + 8 * g * L;
+        for (int g = 0; g < 4; ++g) {
+          float* const pg = ot + static_cast<unsigned>(hq) + 8 * g * L;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if (nstore == kTile || 8 * g + j + h4 < nstore) {
+          for (int j = 0; j < 4; ++j) {
             float pc[NFB];
             tile_get_piece<L>(t, 4 * g + j, pc);
             piece_store<L>(pg + j * L, pc);
           }
         }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          if (8 * (i >> 2) + (i & 3) + h4 < nstore) {
+            float pc[NFB];
+            tile_get_piece<L>(t, i, pc);
+            piece_store<L>(ot + static_cast<unsigned>(hq + (8 * (i >> 2) + (i & 3)) * L), pc);
+          }
+        }
       }
     };
+    STAMP(8);  // bias, act, residual, LayerNorm
+    // the bias of the second projection, fetched before the tile's stores: vector memory completes in order, so a load
+    // issued behind the stores of x' and P_s would make its user wait until those have drained
+    float bv_d[NFB];
+#pragma unroll
+    for (int fb = 0; fb < NFB; ++fb) bv_d[fb] = 0.f;
+    if (!HEAD && a.do_proj) piece_load<L>(a.b0e + NFB * nq, bv_d);
     if (a.x_out && a.do_update) store_tile(a.x_out, v);
     if (!HEAD && a.do_proj) {
       float scale, inv;
       pow2_scale(wave_max(tile_absmax<L>(v)), scale, inv);
       {
+        STAMP(9);  // store x'
         const unsigned char* wl = begin_phase(k++);
+        STAMP(2);
         Tile<L> acc;
         tile_zero<L>(acc);
         if (!DBG(256)) gemm_acc<L, SPLIT, true>(acc, v, scale, win, wo, wl, lane);
@@ -1143,10 +1199,13 @@ __global__ __launch_bounds__(64 * node_waves<L>()) void node_kernel_f2(const Nod
         store_tile(a.Ps, acc);
       }
       {
+        STAMP(10);  // W0s, store P_s
         const unsigned char* wl = begin_phase(k++);
-        // L = 128: x' again, from memory (this wave's own stores of a moment ago, or the input rows): kept in registers
-        // across the previous phase it would push the kernel over its 256 registers (432 bytes of scratch).  L <= 64: kept.
-        if constexpr (L > 64 || AMBER_NODE_RELOAD_V) {
+        STAMP(2);
+        // x' stays in registers across the first projection.  (Round 1 re-read it here at L = 128, the wave's own stores of
+        // a moment ago, for want of registers: with the in-order memory counter that load waited for the stores of x' and
+        // P_s to drain - 14 k of a tile's 113 k cycles.  AMBER_NODE_RELOAD_V brings the re-read back for comparison.)
+        if constexpr (AMBER_NODE_RELOAD_V) {
           const float* const vt = (a.do_update ? a.x_out : a.x_in) + n0 * L;
           AMBER_REPIN_H4;
           if (nvalid == kTile) {
@@ -1174,15 +1233,14 @@ __global__ __launch_bounds__(64 * node_waves<L>()) void node_kernel_f2(const Nod
         if (!DBG(256)) gemm_acc<L, SPLIT, true>(acc, v, scale, win, wo, wl, lane);
         {
           const float post = inv * a.w0d[L * L];
-          float bv[NFB];
-          piece_load<L>(a.b0e + NFB * nq, bv);
 #pragma unroll
           for (int fb = 0; fb < NFB; ++fb) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc.a[fb][i] = fmaf(acc.a[fb][i], post, bv[fb]);
+            for (int i = 0; i < 16; ++i) acc.a[fb][i] = fmaf(acc.a[fb][i], post, bv_d[fb]);
           }
         }
         store_tile(a.Pd, acc);
+        STAMP(11);  // reload x', W0d, store P_d
       }
     }
     // ---- SupervisedMPN head on the updated rows (K9, K10: src/algorithm/architecture/supervised_mpn.py:51-54, MLP
@@ -1231,6 +1289,12 @@ __global__ __launch_bounds__(64 * node_waves<L>()) void node_kernel_f2(const Nod
     }
     }
   }
+#ifdef AMBER_STAMPS
+  if (lane == 0) {
+    for (int k = 0; k < kStamps; ++k) atomicAdd(&g_nstamps[k], static_cast<unsigned long long>(st_acc[k]));
+    atomicAdd(&g_nstamps[kStamps], static_cast<unsigned long long>(st_tiles));
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1393,7 +1457,25 @@ static hipError_t launch_node_f2_t(const NodeArgs& a, int num_cus, hipStream_t s
   if (e != hipSuccess) return e;
   int64_t grid = (num_cus / 8) * 8;  // one persistent workgroup per CU, a multiple of the 8 XCDs
   if (grid < 8) grid = 8;
+#ifdef AMBER_STAMPS
+  unsigned long long zero[kStamps + 1] = {};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_nstamps), zero, sizeof(zero));
+#endif
   hipLaunchKernelGGL((node_kernel_f2<L, SPLIT, HEAD>), dim3(static_cast<unsigned>(grid)), dim3(64 * node_waves<L>()), lds, s, a, ntiles, resident);
+#ifdef AMBER_STAMPS
+  {
+    (void)hipStreamSynchronize(s);
+    unsigned long long got[kStamps + 1] = {};
+    (void)hipMemcpyFromSymbol(got, HIP_SYMBOL(g_nstamps), sizeof(got));
+    static const char* names[kStamps] = {"loop-top", "wait-x", "barriers", "W0x", "wait-agg", "W0a", "bias-act", "hidden", "res-LN", "store-x", "W0s+store", "W0d+store"};
+    double tot = 0;
+    const double nt = static_cast<double>(got[kStamps] ? got[kStamps] : 1);
+    for (int k = 0; k < kStamps; ++k) tot += static_cast<double>(got[k]);
+    fprintf(stderr, "[node stamps L=%d HEAD=%d upd=%d] wave-batches %llu, cycles/batch %.0f:", L, int(HEAD), a.do_update, got[kStamps], tot / nt);
+    for (int k = 0; k < kStamps; ++k) fprintf(stderr, " %s %.0f", names[k], static_cast<double>(got[k]) / nt);
+    fprintf(stderr, "\n");
+  }
+#endif
   return hipGetLastError();
 }
 
