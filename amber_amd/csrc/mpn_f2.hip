@@ -329,9 +329,14 @@ DEVINL WinOff make_win_off(int lane) {
 
 // acc += (tile * scale) x W^T for a tile held as whole row pieces (ELanding): 32 features a pass are split into hi/lo
 // fp16, written to the window as a [row][feature] image and read back as the A operand with ds_read_b128
-template <int L, bool SPLIT, bool PIN = false>
+struct NoPassHook {
+  DEVINL void operator()(int) const {}
+};
+// `after(ps)` runs when pass ps has left its source registers (la.v[ps] / in.a[ps]): the place to issue loads that may
+// land in them, under the pass's MFMAs
+template <int L, bool SPLIT, bool PIN = false, typename F = NoPassHook>
 DEVINL void gemm_rows(Tile<L>& acc, const ELanding<L>& la, float scale, unsigned char* win, const WinOff& o_in,
-                      const unsigned char* wl, int lane) {
+                      const unsigned char* wl, int lane, F&& after = NoPassHook()) {
   WinOff o = o_in;
   if constexpr (PIN) o.pin();
 #pragma unroll
@@ -348,6 +353,7 @@ DEVINL void gemm_rows(Tile<L>& acc, const ELanding<L>& la, float scale, unsigned
       }
       *reinterpret_cast<half4*>(win + o.ew(it)) = hi;
     }
+    after(ps);
     wave_sync();
 #pragma unroll
     for (int sp = 0; sp < 2; ++sp) {
@@ -361,9 +367,9 @@ DEVINL void gemm_rows(Tile<L>& acc, const ELanding<L>& la, float scale, unsigned
 
 // acc += (tile * scale) x W^T for a tile in accumulator layout (feature per lane): 32 features a pass go through the
 // window as a [feature][row] image and come back as the A operand through the transposing read
-template <int L, bool SPLIT, bool PIN = false>
+template <int L, bool SPLIT, bool PIN = false, typename F = NoPassHook>
 DEVINL void gemm_acc(Tile<L>& acc, const Tile<L>& in, float scale, unsigned char* win, const WinOff& o_in,
-                     const unsigned char* wl, int lane) {
+                     const unsigned char* wl, int lane, F&& after = NoPassHook()) {
   WinOff o = o_in;
   if constexpr (PIN) o.pin();
 #pragma unroll
@@ -385,6 +391,7 @@ DEVINL void gemm_acc(Tile<L>& acc, const Tile<L>& in, float scale, unsigned char
       }
       *reinterpret_cast<half4*>(win + o.hw(g)) = hi;
     }
+    after(fb);
     wave_sync();
 #pragma unroll
     for (int sp = 0; sp < 2; ++sp) {
@@ -683,23 +690,39 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
       STAMP(2);  // e rows arrived, tile maximum
       tile_scale<L>(acc, scale * wscale0);
       STAMP(3);  // P_s rows arrived
+    }
+    // destination terms P_d[dst] (rows repeat inside a tile: L1 / L2 hits) join after the contraction, when the landing
+    // registers of e are free again.  (AMBER_PREFETCH_PD fetches a quarter of them after every pass of the contraction
+    // into the landing registers that pass has left: no spill, and 1 % slower - the other wave of the SIMD already covers
+    // these loads.)
+    float pdp[16][NFB];
+    auto load_pd = [&](int ps) {
+      const float* const pdn = a.Pd + NFB * nq;
+#pragma unroll
+      for (int j = 0; j < 16 / NFB; ++j) {
+        const int i = (16 / NFB) * ps + j;
+        const unsigned di = static_cast<unsigned>(row_bcast(dx0, i));
+        piece_load<L>(pdn + static_cast<size_t>(DBG(2) ? 0u : di) * L, pdp[i]);
+      }
+    };
+    if constexpr (EMB) {
+#pragma unroll
+      for (int ps = 0; ps < NFB; ++ps) load_pd(ps);
+    } else {
+#ifdef AMBER_PREFETCH_PD
+      if (!DBG(8)) gemm_rows<L, SPLIT>(acc, la, scale, win, wo, smem, lane, load_pd);
+#else
       if (!DBG(8)) gemm_rows<L, SPLIT>(acc, la, scale, win, wo, smem, lane);
+#pragma unroll
+      for (int ps = 0; ps < NFB; ++ps) load_pd(ps);
+#endif
       us = inv * wsinv0;
     }
     STAMP(4);  // layer 0 contraction
-    // destination terms (rows repeat inside a tile: L1 / L2 hits) join after the contraction, when the landing
-    // registers of e are free again
-    {
-      const float* const pdn = a.Pd + NFB * nq;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const unsigned di = static_cast<unsigned>(row_bcast(dx0, i));
-        float pc[NFB];
-        piece_load<L>(pdn + static_cast<size_t>(DBG(2) ? 0u : di) * L, pc);
+    for (int i = 0; i < 16; ++i)
 #pragma unroll
-        for (int fb = 0; fb < NFB; ++fb) acc.a[fb][i] = fmaf(acc.a[fb][i], us, pc[fb]);
-      }
-    }
+      for (int fb = 0; fb < NFB; ++fb) acc.a[fb][i] = fmaf(acc.a[fb][i], us, pdp[i][fb]);
     tile_act_fast<L>(acc, a.act);
     // Where this half's first row began and its last row ends (rowptr words loaded at the top of the tile).  Taken here,
     // where the in-order memory counter has just been waited down for the P_d rows anyway: read after the stores of e'
@@ -710,58 +733,78 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
     asm volatile("" : "+v"(sb_i), "+v"(ends_last_i));  // evaluated HERE, not sunk to the point of use
     STAMP(5);  // P_d rows, activation
     // ---- hidden layers: the activations go through the window as a [feature][edge] image ----
-#pragma unroll 1
-    for (int l = 1; l < a.nl; ++l) {
+    // The residual rows of e (this wave's own loads of the tile's top, by now in L2 at best).  Fetching them under the
+    // last hidden layer's contraction, a quarter of the tile after every pass into the registers of the layer's input that
+    // the pass has just left (AMBER_PREFETCH_RES), is register-neutral on paper; the compiler spills 70 - 260 registers
+    // over it, so they are fetched after the layer.
+    const bool res_rows = !EMB && a.residual == AMBER_MODE_INNER && !DBG(1);
+    float resp[16][NFB];
+    auto load_res = [&](int ps) {
+#pragma unroll
+      for (int j = 0; j < 16 / NFB; ++j) {
+        const int i = (16 / NFB) * ps + j;
+        if (nvalid == kTile)
+          piece_load<L>(et + static_cast<unsigned>(hq) + kRowGroup<L> * (i / kRowGroup<L>) * L + (i % kRowGroup<L>) * L, resp[i]);
+        else  // rows beyond the end repeat the last edge
+          piece_load<L>(et + static_cast<unsigned>(min(i + 16 * h, rlim) * L + NFB * n), resp[i]);
+      }
+    };
+    // one hidden layer: acc <- act(W_l acc + b_l); `hook(ps)` as in gemm_acc
+    auto hidden_layer = [&](int l, auto&& hook) {
       const float* wg = a.layers[l].w;
+      float bv[NFB];
+      piece_load<L>(a.layers[l].b + NFB * n, bv);  // ahead of the residual rows in the in-order queue
       pow2_scale(wave_max(tile_absmax<L>(acc)), scale, inv);
       // accumulate from zero (the first MFMA of a block takes the constant 0 as its C operand: no 64 moves to seed the
       // accumulators) and add the bias with the multiply that takes the result back out of the scaled domain
       Tile<L> nxt;
       tile_zero<L>(nxt);
-      if (!DBG(8)) gemm_acc<L, SPLIT>(nxt, acc, scale, win, wo, smem + l * MAT_BYTES, lane);
-      {
-        const float post = inv * wg[L * L];
-        float bv[NFB];
-        piece_load<L>(a.layers[l].b + NFB * n, bv);
+      if (!DBG(8)) {
+        gemm_acc<L, SPLIT>(nxt, acc, scale, win, wo, smem + l * MAT_BYTES, lane, hook);
+      } else {
 #pragma unroll
-        for (int fb = 0; fb < NFB; ++fb) {
+        for (int ps = 0; ps < NFB; ++ps) hook(ps);
+      }
+      const float post = inv * wg[L * L];
 #pragma unroll
-          for (int i = 0; i < 16; ++i) nxt.a[fb][i] = fmaf(nxt.a[fb][i], post, bv[fb]);
-        }
+      for (int fb = 0; fb < NFB; ++fb) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) nxt.a[fb][i] = fmaf(nxt.a[fb][i], post, bv[fb]);
       }
       tile_act_fast<L>(nxt, a.act);
       acc = nxt;
+    };
+#pragma unroll 1
+    for (int l = 1; l < a.nl - 1; ++l) hidden_layer(l, NoPassHook());
+#ifdef AMBER_PREFETCH_RES
+    // (the last hidden layer apart from the loop: only it fetches, and inside the loop the fetched rows would be live
+    // through every layer)
+    if (a.nl > 1) {
+      hidden_layer(a.nl - 1, [&](int ps) {
+        if (res_rows) load_res(ps);
+      });
+    } else if (res_rows) {
+#pragma unroll
+      for (int ps = 0; ps < NFB; ++ps) load_res(ps);
     }
+#else
+    if (a.nl > 1) hidden_layer(a.nl - 1, NoPassHook());
+#endif
     STAMP(6);  // hidden layers
     // ---- residual: the rows of e again (this wave's own loads of a moment ago), now feature per lane ----
     if (EMB && a.residual == AMBER_MODE_INNER) {
       Tile<L> e0;
       embed_tile(e0);
       tile_add<L>(acc, e0);
-    } else if (!EMB && a.residual == AMBER_MODE_INNER && !DBG(1)) {
-      if (nvalid == kTile) {
-        // one 64-bit address per group of registers; the rows and feature blocks inside it are immediate offsets
+    } else if (res_rows) {
+#ifndef AMBER_PREFETCH_RES
 #pragma unroll
-        for (int g = 0; g < 16 / kRowGroup<L>; ++g) {
-          const float* const pg = et + static_cast<unsigned>(hq) + kRowGroup<L> * g * L;
+      for (int ps = 0; ps < NFB; ++ps) load_res(ps);
+#endif
 #pragma unroll
-          for (int j = 0; j < kRowGroup<L>; ++j) {
-            float pc[NFB];
-            piece_load<L>(pg + j * L, pc);
+      for (int i = 0; i < 16; ++i)
 #pragma unroll
-            for (int fb = 0; fb < NFB; ++fb) acc.a[fb][kRowGroup<L> * g + j] += pc[fb];
-          }
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          // rows beyond the end repeat the last edge
-          float pc[NFB];
-          piece_load<L>(et + static_cast<unsigned>(min(i + 16 * h, rlim) * L + NFB * n), pc);
-#pragma unroll
-          for (int fb = 0; fb < NFB; ++fb) acc.a[fb][i] += pc[fb];
-        }
-      }
+        for (int fb = 0; fb < NFB; ++fb) acc.a[fb][i] += resp[i][fb];
     }
     if constexpr (PIPE) {  // the next tile's opening loads, behind which the rest of this tile runs
       __builtin_amdgcn_sched_barrier(0);  // not above the residual loads: their landing registers are free only now
