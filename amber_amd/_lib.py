@@ -114,6 +114,20 @@ SIGNATURES = {
                                     _P, _SZ, _P]),
 }
 
+def csrc_hash() -> str:
+    """Content hash of the kernel sources (amber_amd/csrc/*.hip, *.h): stamps counter figures taken from one build
+    (profiles/traffic.json) so that bench.py does not report them for another."""
+    import glob
+    import hashlib
+
+    h = hashlib.sha256()
+    csrc = os.path.join(_HERE, "csrc")
+    for f in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 _lib = None
 
 

@@ -205,10 +205,15 @@ def _sync_flat_gradient(flat_grad: torch.Tensor) -> None:
         return
     if flat_grad.is_cuda and dist.get_backend() == "gloo":
         # gloo is a host backend (CPU tests, one-GPU rehearsals of the multi-rank path).  Stage through the host here:
-        # gloo's own staging of device tensors was seen to hang on ROCm when the stream still had kernels queued.
-        host = flat_grad.cpu()
-        dist.all_reduce(host, op=dist.ReduceOp.SUM)
-        flat_grad.copy_(host)
+        # handed the device tensor, gloo parked both ranks of a rehearsal in all_reduce (DESIGN.md section 6 records what
+        # one diagnostic run with AMBER_GLOO_DEVICE_ALLREDUCE=sync - a stream synchronise, then the device tensor - showed).
+        if os.environ.get("AMBER_GLOO_DEVICE_ALLREDUCE") == "sync":
+            torch.cuda.current_stream(flat_grad.device).synchronize()
+            dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
+        else:
+            host = flat_grad.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            flat_grad.copy_(host)
     else:
         dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)  # RCCL over xGMI on the GPU box (backend "nccl"); one bucket
     if grad_sync == "mean":

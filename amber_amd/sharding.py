@@ -1,10 +1,11 @@
 """Graph-wise data parallelism for disjoint mesh-graph batches.
 
 A PyG batch is a disjoint union: graphs never exchange messages, so the forward shards at graph boundaries with
-NO collective.  Each rank takes a contiguous group of graphs balanced on sum(N_g + E_g) (the size measure of the
+NO collective.  Each rank takes a group of graphs balanced on sum(N_g + E_g) (the size measure of the
 reference's batcher, /root/reference/src/algorithm/dataloader/graph_batcher.py:34-41), re-bases node ids, builds
-its own CSR and runs the full forward; outputs concatenate in graph order.  A single graph is never split
-("replicas only" for that case).
+its own CSR and runs the full forward; outputs are put back in graph order.  The groups are contiguous cuts of
+the batch unless a longest-processing-time assignment balances better (ragged graph sizes); a single graph is
+never split ("replicas only" for that case).
 """
 from __future__ import annotations
 
@@ -34,6 +35,36 @@ def partition_contiguous(weights: Sequence[int], parts: int) -> List[Tuple[int, 
     return [(bounds[k], bounds[k + 1]) for k in range(parts)]
 
 
+def partition_lpt(weights: Sequence[int], parts: int) -> List[List[int]]:
+    """Longest-processing-time assignment: graphs by descending size, each to the least loaded part (ties: the
+    lower part).  Returns the graph ids of every part in ascending order.  Deterministic: every rank computes the same."""
+    w = np.asarray(weights, dtype=np.float64)
+    order = np.argsort(-w, kind="stable")
+    loads = np.zeros(parts)
+    groups: List[List[int]] = [[] for _ in range(parts)]
+    for g in order:
+        k = int(np.argmin(loads))
+        groups[k].append(int(g))
+        loads[k] += w[g]
+    return [sorted(g) for g in groups]
+
+
+def imbalance(weights: Sequence[int], groups: Sequence[Sequence[int]]) -> float:
+    """max part load / mean part load - 1 (0 = perfectly balanced; the ideal speed-up is parts / (1 + imbalance))."""
+    w = np.asarray(weights, dtype=np.float64)
+    loads = np.array([w[list(g)].sum() for g in groups])
+    mean = w.sum() / max(len(groups), 1)
+    return float(loads.max() / mean - 1.0) if mean > 0 else 0.0
+
+
+def assign_graphs(weights: Sequence[int], parts: int) -> List[List[int]]:
+    """Graph ids per rank: the contiguous cut (slices of the batch, no gather of rows) unless the LPT assignment is
+    better balanced by more than one percent of the mean load."""
+    cont = [list(range(lo, hi)) for lo, hi in partition_contiguous(weights, parts)]
+    lpt = partition_lpt(weights, parts)
+    return lpt if imbalance(weights, lpt) + 0.01 < imbalance(weights, cont) else cont
+
+
 def graph_sizes(batch) -> Tuple[np.ndarray, np.ndarray, np.ndarray, np.ndarray]:
     """(ptr[G+1], edge_ptr[G+1], nodes per graph, edges per graph) of a batch.  Uses `ptr` / `edge_ptr` when present,
     otherwise derives them from the `batch` vector (edges are grouped by graph in a PyG batch)."""
@@ -53,20 +84,57 @@ def graph_sizes(batch) -> Tuple[np.ndarray, np.ndarray, np.ndarray, np.ndarray]:
     return ptr, eptr, np.diff(ptr), np.diff(eptr)
 
 
-def shard_batch(batch, rank: int, world_size: int) -> GraphBatch:
-    """The sub-batch of `rank`: its graphs' nodes and edges with node ids re-based to start at 0."""
+def shard_batch(batch, rank: int, world_size: int, balance: str = "auto") -> GraphBatch:
+    """The sub-batch of `rank`: its graphs' nodes and edges with node ids re-based to start at 0.
+    balance: "contiguous" = slices of the batch; "lpt"; "auto" = assign_graphs' choice.  `graph_ids` of the result
+    lists the graphs it holds (ascending)."""
     ptr, eptr, n_g, e_g = graph_sizes(batch)
-    lo, hi = partition_contiguous(n_g + e_g, world_size)[rank]
-    n0, n1, e0, e1 = int(ptr[lo]), int(ptr[hi]), int(eptr[lo]), int(eptr[hi])
+    w = n_g + e_g
+    if balance == "contiguous":
+        ids = [list(range(lo, hi)) for lo, hi in partition_contiguous(w, world_size)][rank]
+    elif balance == "lpt":
+        ids = partition_lpt(w, world_size)[rank]
+    else:
+        ids = assign_graphs(w, world_size)[rank]
+    contiguous = len(ids) == 0 or ids == list(range(ids[0], ids[-1] + 1))
+    if contiguous:
+        lo, hi = (ids[0], ids[-1] + 1) if ids else (0, 0)
+        n0, n1, e0, e1 = int(ptr[lo]), int(ptr[hi]), int(eptr[lo]), int(eptr[hi])
+        out = GraphBatch(
+            x=batch.x[n0:n1], edge_attr=batch.edge_attr[e0:e1], edge_index=batch.edge_index[:, e0:e1] - n0,
+            ptr=torch.from_numpy(ptr[lo:hi + 1] - n0), edge_ptr=torch.from_numpy(eptr[lo:hi + 1] - e0),
+            graph_range=(lo, hi), node_range=(n0, n1), graph_ids=ids)
+        if getattr(batch, "batch", None) is not None:
+            out.batch = batch.batch[n0:n1] - lo
+        if getattr(batch, "mask_output", None) is not None:
+            out.mask_output = batch.mask_output[n0:n1]
+        return out
+    # a scattered set of graphs: gather their rows, shift every graph's node ids from its old to its new offset
+    dev = batch.x.device
+    new_ptr = np.concatenate([[0], np.cumsum(n_g[ids])]).astype(np.int64)
+    new_eptr = np.concatenate([[0], np.cumsum(e_g[ids])]).astype(np.int64)
+    node_idx = torch.from_numpy(np.concatenate([np.arange(ptr[g], ptr[g + 1]) for g in ids])).to(dev)
+    edge_idx = torch.from_numpy(np.concatenate([np.arange(eptr[g], eptr[g + 1]) for g in ids])).to(dev)
+    shift = torch.from_numpy(np.repeat(new_ptr[:-1] - ptr[ids], e_g[ids])).to(dev)
     out = GraphBatch(
-        x=batch.x[n0:n1], edge_attr=batch.edge_attr[e0:e1], edge_index=batch.edge_index[:, e0:e1] - n0,
-        ptr=torch.from_numpy(ptr[lo:hi + 1] - n0), edge_ptr=torch.from_numpy(eptr[lo:hi + 1] - e0),
-        graph_range=(lo, hi), node_range=(n0, n1))
-    if getattr(batch, "batch", None) is not None:
-        out.batch = batch.batch[n0:n1] - lo
+        x=batch.x[node_idx], edge_attr=batch.edge_attr[edge_idx], edge_index=batch.edge_index[:, edge_idx] + shift,
+        ptr=torch.from_numpy(new_ptr), edge_ptr=torch.from_numpy(new_eptr), graph_ids=ids)
+    out.batch = torch.from_numpy(np.repeat(np.arange(len(ids)), n_g[ids])).to(dev)
     if getattr(batch, "mask_output", None) is not None:
-        out.mask_output = batch.mask_output[n0:n1]
+        out.mask_output = batch.mask_output[node_idx]
     return out
+
+
+def shard_stats(batch, world_size: int, balance: str = "auto") -> dict:
+    """What every rank gets: nodes / edges per rank, imbalance of the N + E measure, ideal speed-up of the partition."""
+    ptr, eptr, n_g, e_g = graph_sizes(batch)
+    w = n_g + e_g
+    groups = {"contiguous": lambda: [list(range(lo, hi)) for lo, hi in partition_contiguous(w, world_size)],
+              "lpt": lambda: partition_lpt(w, world_size)}.get(balance, lambda: assign_graphs(w, world_size))()
+    imb = imbalance(w, groups)
+    return {"nodes_per_rank": [int(n_g[g].sum()) for g in groups], "edges_per_rank": [int(e_g[g].sum()) for g in groups],
+            "graphs_per_rank": [len(g) for g in groups], "imbalance_pct": 100.0 * imb,
+            "ideal_speedup": world_size / (1.0 + imb)}
 
 
 def sharded_forward(forward_fn: Callable, batch, rank: int, world_size: int, gather: bool = True,
@@ -76,7 +144,8 @@ def sharded_forward(forward_fn: Callable, batch, rank: int, world_size: int, gat
     data path: the forward itself needs no communication)."""
     import torch.distributed as dist
 
-    local = forward_fn(shard_batch(batch, rank, world_size))
+    shard = shard_batch(batch, rank, world_size)
+    local = forward_fn(shard)
     if not gather or world_size == 1:
         return local
     # gloo is a host backend (CPU tests, one-GPU rehearsals): stage device tensors through the host ourselves - its own
@@ -91,4 +160,17 @@ def sharded_forward(forward_fn: Callable, batch, rank: int, world_size: int, gat
     buf[: local.shape[0]] = local.to(comm)
     outs = [torch.empty_like(buf) for _ in range(world_size)]
     dist.all_gather(outs, buf, group=group)
-    return torch.cat([o[:s] for o, s in zip(outs, sizes)], dim=0).to(dev)
+    ptr, eptr, n_g, e_g = graph_sizes(batch)
+    groups = assign_graphs(n_g + e_g, world_size)
+    if all(g == list(range(g[0], g[-1] + 1)) for g in groups if g):  # contiguous cuts: rank order is graph order
+        return torch.cat([o[:s] for o, s in zip(outs, sizes)], dim=0).to(dev)
+    # scattered groups: put every graph's rows back at its place (rows a graph contributes = its kept nodes)
+    mask = getattr(batch, "mask_output", None)
+    kept = np.asarray([int(mask[ptr[g]:ptr[g + 1]].sum()) if mask is not None else int(n_g[g]) for g in range(len(n_g))])
+    pieces = [None] * len(n_g)
+    for o, g_ids in zip(outs, groups):
+        off = 0
+        for g in g_ids:
+            pieces[g] = o[off:off + kept[g]]
+            off += kept[g]
+    return torch.cat([p for p in pieces if p is not None], dim=0).to(dev)

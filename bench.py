@@ -8,8 +8,12 @@ already resident in HBM, CSR built once per mesh before the timed region (report
   python bench.py --gpus 1 --steps 10 --warmup 3
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-Graph-wise data parallelism, no data-path collective: by default every rank processes its own 10M-edge batch
-("weak"); --scaling strong shards the ONE 100-graph batch across the ranks at graph boundaries instead.
+Graph-wise data parallelism, no data-path collective.  With N > 1 ranks the default is what BASELINE config 5 asks for,
+STRONG scaling: the ONE 100-graph batch is sharded across the ranks at graph boundaries (shards resident before the
+timed region); the same run then also times the weak form (every rank its own 10M-edge batch) and reports it under
+`weak_scaling`.  --scaling weak makes the weak form the headline instead.
+--workload airfoil1 / cap500k: the regime AMBER's refinement loop runs in (one mesh, or one size-capped training
+batch, per forward; latent 64, 20 MP steps): reports host wall-clock per model(batch) next to device time.
 Rank 0 prints one JSON line.
 """
 import argparse
@@ -25,7 +29,7 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 from amber_amd import csr as csr_mod  # noqa: E402
-from amber_amd import engine, sharding, synthetic as syn  # noqa: E402
+from amber_amd import _lib, engine, sharding, synthetic as syn  # noqa: E402
 from amber_amd.architecture.supervised_mpn import SupervisedMPN  # noqa: E402
 from amber_amd.config import default_architecture  # noqa: E402
 
@@ -46,7 +50,12 @@ def parse():
     ap.add_argument("--variant", choices=["grid", "hetero", "brick"], default="grid",
                     help="grid = BASELINE config 5 (the headline); hetero = grid sides ~ U{80..160} per graph; brick = '3D-like' "
                          "tetrahedralised 19^3 bricks, in-degree ~15 (SURVEY.md section 8d's variants; secondary lines)")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=None,
+                    help="N > 1: strong (default) = the one batch sharded over the ranks, weak = one batch per rank")
+    ap.add_argument("--workload", choices=["config5", "airfoil1", "cap500k"], default="config5",
+                    help="config5 = BASELINE config 5 (the headline); airfoil1 = ONE airfoil-sized mesh graph (144x144 grid: "
+                         "N = 20,736, E = 144,002), latent 64, 20 MP steps (configs 2 / 4: one mesh per forward); cap500k = three "
+                         "of them, the reference batcher's N + E <= 500k cap (config 3)")
     ap.add_argument("--precision", choices=["fp32", "f16x2", "f16"], default=None,
                     help="MLP contraction precision (default f16x2: fp32-grade, 1e-5; f16: reduced, 1e-2; fp32: exact fp32 MFMA)")
     ap.add_argument("--train", action="store_true",
@@ -62,7 +71,10 @@ def parse():
                          "box cannot host RCCL ranks); the printed value is NOT a scaling measurement")
     ap.add_argument("--cpu-graphs", type=int, default=10, help="graphs in the CPU-baseline sample (10 = 1M edges)")
     args = ap.parse_args()
-    defaults = dict(graphs=3, nx=144, ny=144, latent=64, mp_steps=20) if args.train else \
+    if args.scaling is None:
+        args.scaling = "strong" if args.gpus > 1 and args.workload == "config5" and not args.train else "weak"
+    small = {"airfoil1": 1, "cap500k": 3}.get(args.workload)
+    defaults = dict(graphs=small or 3, nx=144, ny=144, latent=64, mp_steps=20) if (args.train or small) else \
         dict(graphs=100, nx=120, ny=120, latent=128, mp_steps=10)
     for k, v in defaults.items():
         if getattr(args, k) is None:
@@ -115,6 +127,20 @@ def eager_gpu_baseline(cfg, state_dict, g, dev):
                       f"peak allocated {peak:.0f} GiB"}
 
 
+def measured_traffic():
+    """(bytes per edge-kernel launch from the PMC passes | None, note)."""
+    tpath = os.path.join(REPO, "profiles", "traffic.json")
+    if not os.path.exists(tpath):
+        return None, "no profiles/traffic.json"
+    try:
+        t = json.load(open(tpath))
+    except Exception as exc:  # noqa: BLE001
+        return None, f"profiles/traffic.json unreadable: {exc}"
+    if t.get("csrc_hash") != _lib.csrc_hash():
+        return None, f"profiles/traffic.json was taken on kernel sources {t.get('csrc_hash')}, this build is {_lib.csrc_hash()}: re-run tools/profile_round.sh"
+    return t.get("edge_kernel_hbm_bytes_per_launch"), t.get("note")
+
+
 def init_ranks(args):
     """(rank, world, device, dist-or-None): one process per GPU, RCCL (backend "nccl") over xGMI."""
     rank = int(os.environ.get("RANK", 0))
@@ -133,6 +159,37 @@ def init_ranks(args):
         else:
             dist.init_process_group("nccl", device_id=dev)
     return rank, world, dev, dist
+
+
+def gather_floats(vals, dist, dev):
+    """[[vals of rank 0], [vals of rank 1], ...] on every rank.  Host tensors under gloo (one-GPU rehearsals): gloo's own
+    staging of device tensors is what hung a rehearsal in round 1; RCCL takes device tensors."""
+    if dist is None:
+        return [list(vals)]
+    comm = torch.device("cpu") if dist.get_backend() == "gloo" else dev
+    mine = torch.tensor(list(vals), dtype=torch.float64, device=comm)
+    outs = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(outs, mine)
+    return [o.cpu().tolist() for o in outs]
+
+
+def timed_steps(step, args, dist, dev):
+    """W untimed warm-up steps, then exactly K steps between barrier + synchronize pairs.  Returns (seconds, last output)."""
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize(dev)
+    t_local = time.perf_counter() - t0  # this rank's own K steps (before waiting for the others)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    return time.perf_counter() - t0, t_local, out
 
 
 def train_bench(args):
@@ -169,21 +226,18 @@ def train_bench(args):
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
     assert torch.isfinite(loss)
-    edges_done = torch.tensor([float(e) * args.steps], device=dev, dtype=torch.float64)
-    t_max = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-    if dist is not None:
-        dist.all_reduce(edges_done, op=dist.ReduceOp.SUM)
-        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+    per_rank = gather_floats([float(e) * args.steps, elapsed], dist, dev)
     if rank == 0:
-        t = float(t_max.item())
+        t = max(r[1] for r in per_rank)
         print(json.dumps({
-            "metric": "mpn_train_step_edges_per_sec", "value": float(edges_done.item()) / t, "unit": "edges/s", "n_gpus": world,
+            "metric": "mpn_train_step_edges_per_sec", "value": sum(r[0] for r in per_rank) / t, "unit": "edges/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": t / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "precision": engine.default_precision, "data": "synthetic",
             "config": {"workload": f"training step (forward with tape, backward, Adam) on {args.graphs} triangulated {args.nx}x{args.ny} "
                                    f"grids per GPU, N={n} E={e}, latent {args.latent}, {args.mp_steps} MP steps, edge_dropout {cfg['edge_dropout']} "
                                    f"with a fresh CSR per step for the kept edges (BASELINE config 3 shape by default)",
-                       "parallelism": f"graph-wise dp{world}, one gradient all-reduce per step"}}), flush=True)
+                       "parallelism": f"graph-wise dp{world}, one gradient all-reduce per step",
+                       "backend": dist.get_backend() if dist is not None else None}}), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 
@@ -209,47 +263,66 @@ def main():
     model = model.to(dev)
 
     # ---- data: synthetic mesh-graph batch, resident in HBM ----
-    seed = 1234 + (rank if args.scaling == "weak" else 0)
-    if args.variant == "brick":
-        g = syn.brick_batch(args.graphs, 19, 19, 19, seed=seed)
+    def make_graph(seed):
+        if args.variant == "brick":
+            return syn.brick_batch(args.graphs, 19, 19, 19, seed=seed)
+        return syn.grid_batch(num_graphs=args.graphs, nx=args.nx, ny=args.ny, seed=seed, hetero=args.variant == "hetero")
+
+    def resident(g):
+        gd = g.to(dev)
+        nn = int(gd.x.shape[0])
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        gd.amber_csr = csr_mod.build_csr(gd.edge_index, nn)  # once per mesh, outside the timed region
+        torch.cuda.synchronize(dev)
+        return gd, nn, int(gd.edge_index.shape[1]), (time.perf_counter() - t0) * 1e3
+
+    strong = args.scaling == "strong" and world > 1
+    shard_info = None
+    if strong:
+        full = make_graph(1234)  # the ONE batch of BASELINE config 5, the same on every rank
+        shard_info = sharding.shard_stats(full, world)
+        g = sharding.shard_batch(full, rank, world)
+        del full
     else:
-        g = syn.grid_batch(num_graphs=args.graphs, nx=args.nx, ny=args.ny, seed=seed, hetero=args.variant == "hetero")
-    if args.scaling == "strong" and world > 1:
-        g = sharding.shard_batch(g, rank, world)
-    gd = g.to(dev)
-    n, e = int(gd.x.shape[0]), int(gd.edge_index.shape[1])
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    gd.amber_csr = csr_mod.build_csr(gd.edge_index, n)  # once per mesh, outside the timed region
-    torch.cuda.synchronize(dev)
-    csr_ms = (time.perf_counter() - t0) * 1e3
+        g = make_graph(1234 + rank)
+    gd, n, e, csr_ms = resident(g)
 
     def step():
         with torch.no_grad():
             return model(gd)
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize(dev)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    torch.cuda.synchronize(dev)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
+    elapsed, t_local, out = timed_steps(step, args, dist, dev)
     assert torch.isfinite(out).all()
+    per_rank = gather_floats([float(e) * args.steps, elapsed, t_local, float(n), float(e)], dist, dev)
+    total_edges, t = sum(r[0] for r in per_rank), max(r[1] for r in per_rank)
 
-    edges_done = torch.tensor([float(e) * args.steps], device=dev, dtype=torch.float64)
-    t_max = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-    if dist is not None:
-        dist.all_reduce(edges_done, op=dist.ReduceOp.SUM)
-        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
-    total_edges, t = float(edges_done.item()), float(t_max.item())
+    # N > 1: the other scaling form in the same run, as a secondary figure
+    secondary = None
+    if world > 1 and args.workload == "config5":
+        if strong:
+            del gd
+            torch.cuda.empty_cache()
+            gd, n2, e2, _ = resident(make_graph(1234 + rank))
+        else:
+            full = make_graph(1234)
+            shard_info = sharding.shard_stats(full, world)
+            del gd
+            torch.cuda.empty_cache()
+            gd, n2, e2, _ = resident(sharding.shard_batch(full, rank, world))
+            del full
+        el2, tl2, out2 = timed_steps(step, args, dist, dev)
+        assert torch.isfinite(out2).all()
+        pr2 = gather_floats([float(e2) * args.steps, el2, tl2], dist, dev)
+        t2 = max(r[1] for r in pr2)
+        secondary = {"scaling": "weak" if strong else "strong", "value": sum(r[0] for r in pr2) / t2, "unit": "edges/s",
+                     "ms_per_step": t2 / args.steps * 1e3, "global_edges_per_step": sum(r[0] for r in pr2) / args.steps,
+                     "rank_ms_per_step_min": min(r[2] for r in pr2) / args.steps * 1e3,
+                     "rank_ms_per_step_max": max(r[2] for r in pr2) / args.steps * 1e3}
+        if strong:  # back to the headline's shard for the per-kernel figures below
+            del gd
+            torch.cuda.empty_cache()
+            gd, n, e, _ = resident(g)
 
     # ---- per-kernel device time, measured live with HIP events on the launch stream (rank 0) ----
     roofline = roofline_hbm = kernels = cpu = eager = None
@@ -284,20 +357,26 @@ def main():
         flops_useful = e * 4.0 * L * L
         ach_gbs = bytes_per_launch / (edge_ms * 1e-3) / 1e9
         ach_tf_exec = 3.0 * flops_useful / (edge_ms * 1e-3) / 1e12
-        traffic = None
-        tpath = os.path.join(REPO, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get("edge_kernel_hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        traffic, traffic_note = measured_traffic()
         roofline = {"kernel": f"edge_kernel_f2<{L}>", "bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": bytes_per_launch,
-                    "avg_launch_ms": edge_ms}
+                    "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
+                    "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": edge_ms}
         roofline_hbm = {"kernel": f"edge_kernel_f2<{L}>", "bound": "mfma", "achieved": ach_tf_exec, "peak": F16_MFMA_PEAK_TFLOPS,
                         "unit": "TFLOP/s", "frac": ach_tf_exec / F16_MFMA_PEAK_TFLOPS,
                         "note": "executed fp16 MFMA flops = 3 x useful E*4L^2 (hi*hi, hi*lo, lo*hi); not the binding roof"}
-        if world == 1 and not args.no_cpu_baseline:
+        # host overhead: wall-clock of one model(batch) call that is waited for (what a refinement loop sees per mesh)
+        lat = []
+        for _ in range(max(5, min(20, args.steps))):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            step()
+            torch.cuda.synchronize(dev)
+            lat.append((time.perf_counter() - t0) * 1e3)
+        lat.sort()
+        kernels["wall_ms_per_call_waited_median"] = lat[len(lat) // 2]
+        kernels["wall_ms_per_call_pipelined"] = per_rank[0][2] / args.steps * 1e3
+        kernels["launches_per_forward"] = sum(cnt) // reps
+        if world == 1 and not args.no_cpu_baseline and args.workload == "config5":
             cpu = cpu_baseline(cfg, state_dict, args)
         if world == 1 and args.eager_baseline:
             eager = eager_gpu_baseline(cfg, state_dict, g, dev)
@@ -306,7 +385,10 @@ def main():
         value = total_edges / t
         bytes_fwd = e * (16 * args.latent + 8) * args.mp_steps + n * 8 * args.latent * args.mp_steps \
             + e * (4 * 2 + 4 * args.latent) + n * (4 * 4 + 4 * args.latent) + n * (4 * args.latent + 4)
-        what = {"grid": f"BASELINE config 5: disjoint batch of {args.graphs} triangulated {args.nx}x{args.ny} grids",
+        small = {"airfoil1": "configs 2 / 4 shape: ONE airfoil-sized mesh graph per forward (", "cap500k": "config 3 shape: one size-capped "
+                 "batch (N + E <= 500k) per forward ("}.get(args.workload)
+        what = {"grid": (small + f"{args.graphs} triangulated {args.nx}x{args.ny} grid(s))") if small else
+                f"BASELINE config 5: disjoint batch of {args.graphs} triangulated {args.nx}x{args.ny} grids",
                 "hetero": f"config 5 'hetero' variant: {args.graphs} triangulated grids with sides ~ U{{80..160}}",
                 "brick": f"config 5 '3D-like' variant: {args.graphs} tetrahedralised 19x19x19 bricks (in-degree ~15)"}[args.variant]
         line = {
@@ -316,11 +398,21 @@ def main():
             "config": {"workload": f"{what} per "
                                    f"{'GPU' if args.scaling == 'weak' else 'job'}, N={n} E={e} on rank 0, F_n=4 F_e=2, latent {args.latent}, "
                                    f"{args.mp_steps} MP steps, inner residual + inner LayerNorm, leakyrelu, decoder + readout",
-                       "global_edges_per_step": total_edges / args.steps, "parallelism": f"graph-wise dp{world}, no collective"},
+                       "global_edges_per_step": total_edges / args.steps, "parallelism": f"graph-wise dp{world}, no collective",
+                       "backend": dist.get_backend() if dist is not None else None,
+                       "world_size": dist.get_world_size() if dist is not None else 1},
             "edge_steps_per_sec": value * args.mp_steps,
             "hbm_roofline_frac_whole_forward": (bytes_fwd / (t / args.steps)) / (HBM_PEAK_GBS * 1e9) if world == 1 else None,
             "roofline": roofline, "roofline_mfma": roofline_hbm, "kernels": kernels, "cpu_baseline": cpu,
         }
+        if world > 1:
+            line["ranks"] = {"nodes": [int(r[3]) for r in per_rank], "edges": [int(r[4]) for r in per_rank],
+                             "ms_per_step_min": min(r[2] for r in per_rank) / args.steps * 1e3,
+                             "ms_per_step_max": max(r[2] for r in per_rank) / args.steps * 1e3}
+            if shard_info is not None:
+                line["ranks"]["partition_of_the_one_batch"] = shard_info  # graphs / nodes / edges per rank, imbalance %, ideal speed-up
+            if secondary is not None:
+                line[secondary["scaling"] + "_scaling"] = secondary
         if eager is not None:
             line["eager_gpu_baseline"] = eager
         print(json.dumps(line), flush=True)

@@ -15,6 +15,9 @@ import os
 import sys
 from collections import defaultdict
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from amber_amd._lib import csrc_hash  # noqa: E402
+
 
 def short(name):
     for key in ("edge_kernel", "node_kernel", "embed_kernel", "pack_kernel", "csr_", "segment_mean", "permute_rows"):
@@ -74,7 +77,7 @@ def main(src, dst_prefix):
     edge = [k for k in summary if k.startswith("edge_kernel")]
     if edge and "hbm_bytes_corrected" in summary[edge[0]]:
         json.dump({"edge_kernel_hbm_bytes_per_launch": summary[edge[0]]["hbm_bytes_corrected"],
-                   "source": os.path.basename(dst_prefix) + "_rocprof_summary.txt",
+                   "source": os.path.basename(dst_prefix) + "_rocprof_summary.txt", "csrc_hash": csrc_hash(),
                    "note": "FETCH_SIZE*1024*2 + WRITE_SIZE*1024, averaged over the edge-kernel launches of one forward"},
                   open(os.path.join(os.path.dirname(dst_prefix) or ".", "traffic.json"), "w"), indent=1)
 
