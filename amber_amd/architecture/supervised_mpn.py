@@ -1,6 +1,7 @@
 """The model AMBER calls (mirror of /root/reference/src/algorithm/architecture/supervised_mpn.py:10-56):
 MPN -> x[mask_output] -> decoder MLP -> readout Linear(L, 1), as one call into libamber_mpn.so."""
 import ctypes as C
+import weakref
 
 import torch
 import torch.nn as nn
@@ -24,28 +25,82 @@ class SupervisedMPN(nn.Module):
         self.decoder_mlp = MLP(in_features=latent_dimension, mlp_config=mlp_config, latent_dimension=latent_dimension)
         self.readout = nn.Linear(latent_dimension, 1)
         self._packed = engine.PackedParams()
+        self._plans = {}          # per call shape: descriptor + the module walk's tensor lists (see _plan)
+        self._mask_cache = None   # (weakref(mask), version, out_index, n_out)
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module._plans.clear())
+
+    # ---- host-side caches: one mesh per forward (AMBER's refinement loop) is 42 launches of ~30 us; walking ~250
+    # parameter tensors through nn.Module.__getattr__ (0.4 ms) and a device->host read of the mask count per call would
+    # show up next to that ----
+    def _apply(self, fn, *args, **kwargs):  # .to() / .cuda() / .float(): parameters are re-created
+        self._plans.clear()
+        return super()._apply(fn, *args, **kwargs)
+
+    def train(self, mode: bool = True):
+        self._plans.clear()
+        return super().train(mode)
+
+    def _plan(self, single_row: bool):
+        """(desc, flat-buffer pieces, key tensors).  The lists are cached while the decoder's pieces ARE its parameters
+        (no BatchNorm folding, no spectral norm: those derive temporaries per call); `_apply`, `train()` and
+        `load_state_dict` drop the cache.  PackedParams still checks every tensor's data pointer and version per call.
+        Not noticed: assigning a NEW Parameter object to a sub-module after the first forward - call `model._plans.clear()`."""
+        key = (single_row, engine.default_precision)
+        plan = self._plans.get(key)
+        if plan is not None:
+            return plan
+        dec = self.decoder_mlp
+        desc = engine.make_desc(has_head=True, decoder_layers=dec.num_layers, decoder_activation=dec.activation_function,
+                                decoder_norm=dec.latent_normalization, **self.mpn.desc_kwargs())
+        dec_pieces, dec_sources = dec.param_list(single_row=single_row)
+        base = self.mpn.param_list()
+        tail = [self.readout.weight, self.readout.bias]
+        plan = (desc, base, dec_pieces, dec_sources, tail)
+        if len(dec_pieces) == len(dec_sources) and all(a is b for a, b in zip(dec_pieces, dec_sources)):
+            self._plans[key] = plan
+        return plan
+
+    def _out_index(self, observations, n):
+        """x[mask_output] as (out_index, n_out); remembered per mask tensor (identity + version), so that a repeated
+        forward on one graph does not read the kept-node count back from the device each time."""
+        if not hasattr(observations, "mask_output"):
+            return None, n
+        mask = observations.mask_output
+        hit = self._mask_cache
+        if hit is not None and hit[0]() is mask and hit[1] == mask._version:
+            return hit[2], hit[3]
+        out_index, n_out = engine.out_index_from_mask(mask)
+        self._mask_cache = (weakref.ref(mask), mask._version, out_index, n_out)
+        return out_index, n_out
+
+    def _check_train_mode_decoder(self):
+        """In train() mode the reference's decoder applies dropout and BatchNorm batch statistics (and updates the running
+        buffers) whatever the autograd mode (mlp.py:128-129).  The kernels implement the eval-mode forms only, so those
+        configurations raise in train() mode - also under torch.no_grad() or with frozen parameters - instead of
+        returning eval-mode numbers."""
+        if not self.training:
+            return
+        for m in self.decoder_mlp.mlp_layers:
+            if isinstance(m, nn.Dropout) and m.p > 0:
+                raise NotImplementedError("amber_amd: decoder dropout is not built for train() mode (call model.eval() for inference)")
+            if isinstance(m, nn.BatchNorm1d):
+                raise NotImplementedError("amber_amd: decoder BatchNorm (batch statistics, running-buffer updates) is not built "
+                                          "for train() mode (call model.eval() for inference)")
 
     def forward(self, observations, **kwargs) -> torch.Tensor:
         """observations: (batch of) observation graph(s) on the GPU.  Returns one scalar per kept node,
         shape [N_masked, 1] (all nodes when the batch has no `mask_output`)."""
+        self._check_train_mode_decoder()
         observations, csr = self.mpn.prepare(observations)
         n = csr.num_nodes
-        out_index, n_out = None, n
-        if hasattr(observations, "mask_output"):
-            out_index, n_out = engine.out_index_from_mask(observations.mask_output)
+        out_index, n_out = self._out_index(observations, n)
         dec = self.decoder_mlp
-        desc = engine.make_desc(has_head=True, decoder_layers=dec.num_layers, decoder_activation=dec.activation_function,
-                                decoder_norm=dec.latent_normalization, **self.mpn.desc_kwargs())
-        dec_pieces, dec_sources = dec.param_list(single_row=(n_out == 1))
-        base = self.mpn.param_list()
-        tail = [self.readout.weight, self.readout.bias]
+        desc, base, dec_pieces, dec_sources, tail = self._plan(single_row=(n_out == 1))
         if engine.wants_grad(base + dec_sources + tail):  # training step (src/algorithm/core/amber.py:62-82)
-            if self.training and any(isinstance(m, nn.Dropout) and m.p > 0 for m in dec.mlp_layers):
-                raise NotImplementedError("amber_amd: decoder dropout is not built for training")
             if dec.latent_normalization is not None:
                 raise NotImplementedError("amber_amd: decoder latent_normalization is not built for training")
             return engine.MpnFunction.apply(desc, self._packed, observations.x, observations.edge_attr, csr, out_index, n_out,
-                                            False, False, *(base + dec_pieces + tail))[2]
+                                            False, False, base + dec_sources + tail, *(base + dec_pieces + tail))[2]
         flat, packed = self._packed.get(desc, base + dec_pieces + tail, key_tensors=base + dec_sources + tail
                                         + ([self.readout.bias] if n_out == 1 else []))
         _, _, out = engine.forward(desc, flat, packed, observations.x, observations.edge_attr, csr, want_node=False,
@@ -55,17 +110,11 @@ class SupervisedMPN(nn.Module):
     def fused_predict(self, observations, glue_desc, node_normalizer, edge_normalizer, prediction_normalizer, baseline) -> torch.Tensor:
         """amber_mpn_predict: input normalisation + forward + post-processing of the readout in one C call (inference;
         see amber_amd.predict.predict).  The *_normalizer arguments are TorchRunningMeanStd modules or None."""
+        self._check_train_mode_decoder()
         observations, csr = self.mpn.prepare(observations)
         n, e = csr.num_nodes, csr.num_edges
-        out_index, n_out = None, n
-        if hasattr(observations, "mask_output"):
-            out_index, n_out = engine.out_index_from_mask(observations.mask_output)
-        dec = self.decoder_mlp
-        desc = engine.make_desc(has_head=True, decoder_layers=dec.num_layers, decoder_activation=dec.activation_function,
-                                decoder_norm=dec.latent_normalization, **self.mpn.desc_kwargs())
-        dec_pieces, dec_sources = dec.param_list(single_row=(n_out == 1))
-        base = self.mpn.param_list()
-        tail = [self.readout.weight, self.readout.bias]
+        out_index, n_out = self._out_index(observations, n)
+        desc, base, dec_pieces, dec_sources, tail = self._plan(single_row=(n_out == 1))
         flat, packed = self._packed.get(desc, base + dec_pieces + tail, key_tensors=base + dec_sources + tail
                                         + ([self.readout.bias] if n_out == 1 else []))
         x, edge_attr = observations.x, observations.edge_attr

@@ -263,6 +263,26 @@ struct Timer {
   }
 };
 
+// Debug switches of the environment, read ONCE per process: the packed-buffer layout depends on them (use_fast_head), so
+// a value that changed between amber_mpn_pack_weights and a forward would make the kernels read the wrong matrices.
+struct EnvSwitches {
+  bool no_fused_head, no_fused_embed;
+  EnvSwitches() : no_fused_head(getenv("AMBER_MPN_NO_FUSED_HEAD") != nullptr), no_fused_embed(getenv("AMBER_MPN_NO_FUSED_EMBED") != nullptr) {}
+};
+const EnvSwitches& env_switches() {
+  static const EnvSwitches e;
+  return e;
+}
+// kernel-variant timing switches (tools/exp_dbg.py): only in builds that compile them in, and then read per call
+int dbg_switches() {
+#ifdef AMBER_DBG_SWITCHES
+  const char* dbg = getenv("AMBER_MPN_DBG");
+  return dbg ? atoi(dbg) : 0;
+#else
+  return 0;
+#endif
+}
+
 bool use_fast_edge(const AmberMpnDesc& d) {
   return d.precision != AMBER_PREC_FP32 && edge_f2_supported(d.latent, d.mlp_layers, d.activation, d.residual, d.layer_norm);
 }
@@ -272,12 +292,16 @@ bool use_fast_node(const AmberMpnDesc& d) {
 // the head rides on the last split-precision node launch (decoder layers as further phases, readout in the epilogue)
 bool use_fast_head(const AmberMpnDesc& d) {
   return d.has_head && use_fast_node(d) && d.num_steps * d.num_step_repeats > 0 &&
-         head_f2_supported(d.decoder_layers, d.decoder_activation, d.decoder_norm) && !getenv("AMBER_MPN_NO_FUSED_HEAD");
+         head_f2_supported(d.decoder_layers, d.decoder_activation, d.decoder_norm) && !env_switches().no_fused_head;
 }
 int device_cus() {
+  constexpr int kMaxDevices = 64;
+  static int cached[kMaxDevices] = {};  // 0 = not asked yet (benign race: every thread stores the same value)
   int dev = 0, cus = 0;
   if (hipGetDevice(&dev) != hipSuccess) return 256;
+  if (dev >= 0 && dev < kMaxDevices && cached[dev] > 0) return cached[dev];
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return 256;
+  if (dev >= 0 && dev < kMaxDevices) cached[dev] = cus;
   return cus;
 }
 hipError_t run_edge(const AmberMpnDesc& d, EdgeArgs& ea, hipStream_t s) {
@@ -295,8 +319,7 @@ hipError_t run_edge(const AmberMpnDesc& d, EdgeArgs& ea, hipStream_t s) {
 hipError_t run_node(const AmberMpnDesc& d, const NodeArgs& na, hipStream_t s) {
   if (!na.fast) return launch_node(d.latent, na, s);
   NodeArgs u = na;
-  const char* dbg = getenv("AMBER_MPN_DBG");
-  u.dbg = dbg ? atoi(dbg) : 0;
+  u.dbg = dbg_switches();
   u.single = d.precision == AMBER_PREC_F16 ? 1 : 0;
   // the head joins this launch when its matrices exist in the split-precision format and the update runs here too
   const bool head_here = na.do_readout && na.do_update && !na.dense_out && na.n_dense > 0 && na.dense_f2[0] != nullptr;
@@ -330,8 +353,7 @@ void fill_edge_step(EdgeArgs& a, const AmberMpnDesc& d, const Layout& lay, int s
   a.gamma = d.layer_norm != AMBER_MODE_NONE ? params + lay.eg[step] : nullptr;
   a.beta = d.layer_norm != AMBER_MODE_NONE ? params + lay.eb[step] : nullptr;
   a.eps = d.ln_eps;
-  const char* dbg = getenv("AMBER_MPN_DBG");
-  a.dbg = dbg ? atoi(dbg) : 0;
+  a.dbg = dbg_switches();
 }
 void fill_node_update(NodeArgs& a, const AmberMpnDesc& d, const Layout& lay, int step, const float* params, const float* packed) {
   const MlpLayout& m = lay.node[step];
@@ -440,7 +462,7 @@ int forward_impl(const AmberMpnDesc* desc, const float* params, const float* pac
   // The linear (or constant) edge embedding of few raw features is fused into the first edge step: its rows are
   // computed there on the fly and e is first written by that step.
   const bool fuse_edge_embed = !tape && iters > 0 && use_fast_edge(d) && d.in_edge_features <= kMaxFusedEmbed &&
-                               (d.in_edge_features == 0 || d.embed_layers == 0) && !getenv("AMBER_MPN_NO_FUSED_EMBED");
+                               (d.in_edge_features == 0 || d.embed_layers == 0) && !env_switches().no_fused_embed;
   if (!fuse_edge_embed) {
     rc = run_embedding(d, lay.edge_embed, d.in_edge_features, params, packed, edge_attr, E, perm, ebuf(0), s, tm);
     if (rc) return rc;

@@ -1421,6 +1421,35 @@ hipError_t launch_pack_f2(int L, const float* W, int ld, int col0, int scale_col
   return launch_pack_f2_batch(L, b, s);
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize once per (kernel, device, size): a runtime call per launch is what a
+// forward on a small graph (42 launches of ~30 us) can do without
+static hipError_t allow_dynamic_lds(const void* fn, size_t lds) {
+  struct Seen {
+    const void* fn;
+    int dev;
+    size_t lds;
+  };
+  static thread_local Seen seen[64];
+  static thread_local int nseen = 0;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  for (int i = 0; i < nseen; ++i)
+    if (seen[i].fn == fn && seen[i].dev == dev && seen[i].lds >= lds) return hipSuccess;
+  e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+  if (e != hipSuccess) return e;
+  if (nseen < 64) seen[nseen++] = Seen{fn, dev, lds};
+  return hipSuccess;
+}
+// Persistent grid: one workgroup per CU, a multiple of the 8 XCDs - but no more workgroups than there are tiles to hand
+// every wave one (small graphs: a workgroup without a tile would still load the layer weights into its LDS).
+static int64_t persistent_grid(int num_cus, int64_t ntiles, int waves) {
+  int64_t grid = (num_cus / 8) * 8;
+  if (grid < 8) grid = 8;
+  const int64_t need = ((ntiles + waves - 1) / waves + 7) / 8 * 8;
+  return need < grid ? (need < 8 ? 8 : need) : grid;
+}
+
 size_t edge_f2_lds_bytes(int L, int nl) {
   const int waves = L == 64 ? edge_waves<64>() : (L == 32 ? edge_waves<32>() : kF2Waves);
   return static_cast<size_t>(nl) * L * L * 4 + static_cast<size_t>(waves) * kWinBytes;
@@ -1436,11 +1465,9 @@ static hipError_t launch_edge_f2_t(const EdgeArgs& a, int num_cus, hipStream_t s
   const int64_t ntiles = (a.E + kTile - 1) / kTile;
   if (ntiles == 0) return hipSuccess;
   const size_t lds = edge_f2_lds_bytes(L, a.nl);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(edge_kernel_f2<L, EMB, SPLIT>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+  hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(edge_kernel_f2<L, EMB, SPLIT>), lds);
   if (e != hipSuccess) return e;
-  int64_t grid = (num_cus / 8) * 8;  // one persistent workgroup per CU, a multiple of the 8 XCDs
-  if (grid < 8) grid = 8;
+  const int64_t grid = persistent_grid(num_cus, ntiles, edge_waves<L>());
 #ifdef AMBER_STAMPS
   unsigned long long zero[kStamps + 1] = {};
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), zero, sizeof(zero));
@@ -1495,11 +1522,9 @@ static hipError_t launch_node_f2_t(const NodeArgs& a, int num_cus, hipStream_t s
   const size_t mat = static_cast<size_t>(L) * L * 4, wins = static_cast<size_t>(node_waves<L>()) * kWinBytes;
   const int resident = P * mat + wins <= 160 * 1024 ? 1 : 0;
   const size_t lds = (resident ? P : 2) * mat + wins;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(node_kernel_f2<L, SPLIT, HEAD>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     static_cast<int>(lds));
+  hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(node_kernel_f2<L, SPLIT, HEAD>), lds);
   if (e != hipSuccess) return e;
-  int64_t grid = (num_cus / 8) * 8;  // one persistent workgroup per CU, a multiple of the 8 XCDs
-  if (grid < 8) grid = 8;
+  const int64_t grid = persistent_grid(num_cus, ntiles, node_waves<L>());
 #ifdef AMBER_STAMPS
   unsigned long long zero[kStamps + 1] = {};
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_nstamps), zero, sizeof(zero));

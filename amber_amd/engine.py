@@ -225,7 +225,11 @@ class MpnFunction(torch.autograd.Function):
     Inputs x / edge_attr are data and get no gradient."""
 
     @staticmethod
-    def forward(ctx, desc, packer: PackedParams, x, edge_attr, csr: CSR, out_index, n_out, want_node, want_edge, *params):
+    def forward(ctx, desc, packer: PackedParams, x, edge_attr, csr: CSR, out_index, n_out, want_node, want_edge, key_tensors,
+                *params):
+        """key_tensors: the module's own parameters / buffers the cache key is built from (None: `params`).  Derived
+        temporaries among `params` (a spectrally normalised weight is a fresh tensor every forward, and the allocator
+        hands the same address out again) must not key the cache."""
         lib = _lib.load()
         _require_cuda(x, "x")
         _require_cuda(edge_attr, "edge_attr")
@@ -234,7 +238,7 @@ class MpnFunction(torch.autograd.Function):
         n, e, latent = csr.num_nodes, csr.num_edges, desc.latent
         if x.shape[0] != n or edge_attr.shape[0] != e:
             raise ValueError(f"Must provide one edge index per edge feature vector, given '{(2, e)}' and '{tuple(edge_attr.shape)}' instead.")
-        flat, packed = packer.get(desc, params)
+        flat, packed = packer.get(desc, params, key_tensors=key_tensors)
         out_node = torch.empty(n, latent, dtype=torch.float32, device=dev) if want_node else None
         out_edge = torch.empty(e, latent, dtype=torch.float32, device=dev) if want_edge else None
         out_sizing = torch.empty(n_out, 1, dtype=torch.float32, device=dev) if (desc.has_head and n_out is not None) else None
@@ -292,7 +296,7 @@ class MpnFunction(torch.autograd.Function):
                 k *= d
             grads.append(grad[off:off + k].view(shape))
             off += k
-        return (None,) * 9 + tuple(grads)
+        return (None,) * 10 + tuple(grads)
 
 
 def wants_grad(params: Sequence[torch.Tensor]) -> bool:

@@ -114,7 +114,7 @@ class MessagePassingBase(nn.Module):
         params = self.param_list()
         if engine.wants_grad(params):  # training step: autograd through amber_mpn_forward_train / amber_mpn_backward
             node, edge, _ = engine.MpnFunction.apply(desc, self._packed, graph.x, graph.edge_attr, csr, None, None, True, True,
-                                                     *params)
+                                                     None, *params)
         else:
             flat, packed = self._packed.get(desc, params)
             node, edge, _ = engine.forward(desc, flat, packed, graph.x, graph.edge_attr, csr, want_node=True, want_edge=True)

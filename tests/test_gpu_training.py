@@ -130,6 +130,31 @@ def test_gradients_match_oracle_autograd(gpu_device, latent, steps, layers, kind
     _check_grads(model, want, GRAD_TOL if act == "tanh" else KINK_TOL)
 
 
+def test_train_mode_spectral_norm_repacks_on_every_forward(gpu_device):
+    """with a spectrally normalised decoder every train-mode forward runs one power iteration (u, v move in
+    place) and hands the kernels a NEW effective weight tensor - often at the address the previous one had.  Without an
+    optimizer step in between (gradient accumulation) the packed weights must still follow: each forward has to equal the
+    oracle evaluated on the state the forward left behind (weight_orig / (u . W v) with the u, v it produced)."""
+    from amber_amd.architecture.supervised_mpn import SupervisedMPN
+    from amber_amd.config import AttrDict
+
+    cfg = _cfg(32, 1, act="tanh")
+    cfg["decoder"]["regularization"]["spectral_norm"] = True
+    g = syn.grid_batch(num_graphs=2, nx=9, ny=7)
+    torch.manual_seed(3)
+    model = SupervisedMPN(AttrDict(cfg), g).to(gpu_device).train()
+    gd = g.to(gpu_device)
+    outs = []
+    for _ in range(3):  # no optimizer step between the forwards
+        out = model(gd)
+        out.sum().backward()
+        sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+        want = orc.supervised_mpn_forward(sd, cfg, g.x, g.edge_attr, g.edge_index, g.mask_output)
+        assert rel_err(out.detach().cpu(), want) <= 1e-5
+        outs.append(out.detach().cpu())
+    assert not torch.equal(outs[0], outs[1])  # the power iteration did move the weight between the forwards
+
+
 def test_backward_beyond_2_31_latent_elements(gpu_device):
     """E * L = 2.94e9 > 2^31 (230 x 120x120 grids, L = 128, one step): the tape, the backward's row-sized intermediates and
     every offset into them must be 64-bit.  With a loss that only looks at the LAST graph of the batch, the parameter

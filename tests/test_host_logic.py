@@ -67,6 +67,46 @@ def test_decoder_batchnorm_folding_and_module_indices():
     assert len(sources) == 2 * (2 + 4)
 
 
+def test_train_mode_decoder_regularisation_raises_whatever_the_grad_mode():
+    """train() + no_grad (or frozen parameters) must not silently return eval-mode numbers for a decoder with
+    dropout / BatchNorm - the reference applies them in that state (mlp.py:128-129)."""
+    g = syn.grid_batch(num_graphs=1, nx=4, ny=4, in_node_features=3, in_edge_features=2)
+    for reg, msg in (({"dropout": 0.5}, "dropout"), ({"latent_normalization": "batch"}, "BatchNorm")):
+        cfg = default_architecture(latent_dimension=32, num_steps=1)
+        cfg["decoder"]["regularization"].update(reg)
+        model = SupervisedMPN(cfg, g).train()
+        with torch.no_grad(), pytest.raises(NotImplementedError, match=msg):
+            model(g)
+        for p in model.parameters():
+            p.requires_grad_(False)
+        with pytest.raises(NotImplementedError, match=msg):
+            model(g)
+        with pytest.raises(RuntimeError, match="no CPU path"):  # eval mode gets past the check (and then needs the GPU)
+            model.eval()(g)
+
+
+def test_plan_cache_is_dropped_when_parameters_are_recreated():
+    cfg = default_architecture(latent_dimension=32, num_steps=2)
+    g = syn.grid_batch(num_graphs=1, nx=4, ny=4, in_node_features=3, in_edge_features=2)
+    model = SupervisedMPN(cfg, g).eval()
+    plan = model._plan(single_row=False)
+    assert model._plan(single_row=False) is plan  # cached: the decoder's pieces are its parameters
+    assert all(a is b for a, b in zip(plan[1], model.mpn.param_list()))
+    model.double().float()  # _apply re-creates the parameters' data
+    assert model._plans == {}
+    plan2 = model._plan(single_row=False)
+    model.load_state_dict(model.state_dict())
+    assert model._plans == {}
+    model.train()
+    assert model._plans == {}
+    # a decoder that derives its pieces per call (BatchNorm folded to scale / shift) is not cached
+    cfg["decoder"]["regularization"]["latent_normalization"] = "batch"
+    model_bn = SupervisedMPN(cfg, g).eval()
+    model_bn._plan(single_row=False)
+    assert model_bn._plans == {}
+    assert plan2[0].latent == 32
+
+
 def test_factories_and_error_behaviour():
     base_cfg = default_architecture(latent_dimension=32, num_steps=2)
     g = syn.grid_batch(num_graphs=1, nx=4, ny=4, in_node_features=6, in_edge_features=3)
