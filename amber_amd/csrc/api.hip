@@ -58,8 +58,8 @@ struct Layout {
 int validate(const AmberMpnDesc* d) {
   (void)hipGetLastError();  // drop a stale error left by an earlier, unrelated runtime call of this thread
   if (!d) return fail(AMBER_ERR_INVALID_ARGUMENT, "desc is NULL");
-  if (d->latent != 32 && d->latent != 64 && d->latent != 128)
-    return fail(AMBER_ERR_UNSUPPORTED, "latent_dimension %d not supported (32, 64, 128)", d->latent);
+  if (d->latent != 32 && d->latent != 64 && d->latent != 128 && d->latent != 256)
+    return fail(AMBER_ERR_UNSUPPORTED, "latent_dimension %d not supported (32, 64, 128, 256)", d->latent);
   if (d->num_steps < 0 || d->num_step_repeats < 1) return fail(AMBER_ERR_INVALID_ARGUMENT, "bad num_steps / num_step_repeats");
   if (d->mlp_layers < 1 || d->mlp_layers > kMaxLayers)
     return fail(AMBER_ERR_UNSUPPORTED, "stack.mlp.num_layers %d not in 1..%d", d->mlp_layers, kMaxLayers);
@@ -569,6 +569,7 @@ int forward_impl(const AmberMpnDesc* desc, const float* params, const float* pac
 // training: configurations the backward kernels take, workspace, and the launch sequence
 // ---------------------------------------------------------------------------------------------------
 int validate_train(const AmberMpnDesc& d) {
+  if (d.latent > 128) return fail(AMBER_ERR_UNSUPPORTED, "training: latent_dimension %d is not built (32, 64, 128 are)", d.latent);
   if (d.residual == AMBER_MODE_OUTER || d.layer_norm == AMBER_MODE_OUTER)
     return fail(AMBER_ERR_UNSUPPORTED, "training: 'outer' residual / layer_norm is not built (inner and none are)");
   if (d.embed_layers > 0) return fail(AMBER_ERR_UNSUPPORTED, "training: MLP input embeddings are not built (linear / constant are)");

@@ -823,6 +823,7 @@ hipError_t launch_pack_batch(int L, const PackBatch& b, hipStream_t s) {
     case 32: return launch_pack_batch_t<32>(b, s);
     case 64: return launch_pack_batch_t<64>(b, s);
     case 128: return launch_pack_batch_t<128>(b, s);
+    case 256: return launch_pack_batch_t<256>(b, s);  // forward only (amber_mpn_pack_weights): latent 256 has no backward
     default: return hipErrorInvalidValue;
   }
 }

@@ -1506,7 +1506,7 @@ hipError_t launch_edge_f2(int L, const EdgeArgs& a, int num_cus, hipStream_t s) 
 }
 
 bool node_f2_supported(int L, int act, int residual, int layer_norm) {
-  return (act == AMBER_ACT_RELU || act == AMBER_ACT_LEAKYRELU) && residual != AMBER_MODE_OUTER && layer_norm != AMBER_MODE_OUTER;
+  return L <= 128 && (act == AMBER_ACT_RELU || act == AMBER_ACT_LEAKYRELU) && residual != AMBER_MODE_OUTER && layer_norm != AMBER_MODE_OUTER;
 }
 
 bool head_f2_supported(int n_dense, int dense_act, int dense_norm) {

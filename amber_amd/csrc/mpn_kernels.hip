@@ -383,6 +383,7 @@ hipError_t launch_edge(int L, const EdgeArgs& a, hipStream_t s) {
     case 32: return launch_edge_t<32>(a, s);
     case 64: return launch_edge_t<64>(a, s);
     case 128: return launch_edge_t<128>(a, s);
+    case 256: return launch_edge_t<256>(a, s);
     default: return hipErrorInvalidValue;
   }
 }
@@ -391,6 +392,7 @@ hipError_t launch_node(int L, const NodeArgs& a, hipStream_t s) {
     case 32: return launch_node_t<32>(a, s);
     case 64: return launch_node_t<64>(a, s);
     case 128: return launch_node_t<128>(a, s);
+    case 256: return launch_node_t<256>(a, s);
     default: return hipErrorInvalidValue;
   }
 }
@@ -400,6 +402,7 @@ hipError_t launch_embed(int L, const float* in, int64_t rows, int F, const float
     case 32: return launch_embed_t<32>(in, rows, F, W, b, perm, act, out, s);
     case 64: return launch_embed_t<64>(in, rows, F, W, b, perm, act, out, s);
     case 128: return launch_embed_t<128>(in, rows, F, W, b, perm, act, out, s);
+    case 256: return launch_embed_t<256>(in, rows, F, W, b, perm, act, out, s);
     default: return hipErrorInvalidValue;
   }
 }
@@ -408,6 +411,7 @@ hipError_t launch_pack(int L, const float* W, int ld, int col0, float* out, hipS
     case 32: return launch_pack_t<32>(W, ld, col0, out, s);
     case 64: return launch_pack_t<64>(W, ld, col0, out, s);
     case 128: return launch_pack_t<128>(W, ld, col0, out, s);
+    case 256: return launch_pack_t<256>(W, ld, col0, out, s);
     default: return hipErrorInvalidValue;
   }
 }

@@ -35,6 +35,7 @@ from amber_amd.config import default_architecture  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 F16_MFMA_PEAK_TFLOPS = 2500.0  # dense fp16 / bf16 MFMA peak (same guide)
+F32_MFMA_PEAK_TFLOPS = 157.3   # fp32-input MFMA = the fp32 vector rate (same guide)
 
 
 def parse():
@@ -358,12 +359,23 @@ def main():
         ach_gbs = bytes_per_launch / (edge_ms * 1e-3) / 1e9
         ach_tf_exec = 3.0 * flops_useful / (edge_ms * 1e-3) / 1e12
         traffic, traffic_note = measured_traffic()
-        roofline = {"kernel": f"edge_kernel_f2<{L}>", "bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
-                    "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": edge_ms}
-        roofline_hbm = {"kernel": f"edge_kernel_f2<{L}>", "bound": "mfma", "achieved": ach_tf_exec, "peak": F16_MFMA_PEAK_TFLOPS,
-                        "unit": "TFLOP/s", "frac": ach_tf_exec / F16_MFMA_PEAK_TFLOPS,
-                        "note": "executed fp16 MFMA flops = 3 x useful E*4L^2 (hi*hi, hi*lo, lo*hi); not the binding roof"}
+        split = engine.default_precision != "fp32" and L <= 128  # the split-precision kernels ran (else: exact fp32 MFMA)
+        if split:
+            roofline = {"kernel": f"edge_kernel_f2<{L}>", "bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
+                        "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": edge_ms}
+            roofline_hbm = {"kernel": f"edge_kernel_f2<{L}>", "bound": "mfma", "achieved": ach_tf_exec, "peak": F16_MFMA_PEAK_TFLOPS,
+                            "unit": "TFLOP/s", "frac": ach_tf_exec / F16_MFMA_PEAK_TFLOPS,
+                            "note": "executed fp16 MFMA flops = 3 x useful E*4L^2 (hi*hi, hi*lo, lo*hi); not the binding roof"}
+        else:
+            # exact fp32 MFMA (v_mfma_f32_32x32x2_f32 runs at the fp32 vector rate): the matrix pipe binds, not HBM
+            ach_tf = flops_useful / (edge_ms * 1e-3) / 1e12
+            roofline = {"kernel": f"edge_kernel<{L}>", "bound": "mfma", "achieved": ach_tf, "peak": F32_MFMA_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": ach_tf / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                        "traffic_note": "exact fp32 path (fp32 mode, or latent 256): E*4L^2 fp32 MFMA flops per launch",
+                        "avg_launch_ms": edge_ms}
+            roofline_hbm = {"kernel": f"edge_kernel<{L}>", "bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": ach_gbs / HBM_PEAK_GBS, "note": "algorithmic bytes E*(16L+8); not the binding roof of the exact path"}
         # host overhead: wall-clock of one model(batch) call that is waited for (what a refinement loop sees per mesh)
         lat = []
         for _ in range(max(5, min(20, args.steps))):
@@ -403,7 +415,7 @@ def main():
                        "world_size": dist.get_world_size() if dist is not None else 1},
             "edge_steps_per_sec": value * args.mp_steps,
             "hbm_roofline_frac_whole_forward": (bytes_fwd / (t / args.steps)) / (HBM_PEAK_GBS * 1e9) if world == 1 else None,
-            "roofline": roofline, "roofline_mfma": roofline_hbm, "kernels": kernels, "cpu_baseline": cpu,
+            "roofline": roofline, "roofline_other": roofline_hbm, "kernels": kernels, "cpu_baseline": cpu,
         }
         if world > 1:
             line["ranks"] = {"nodes": [int(r[3]) for r in per_rank], "edges": [int(r[4]) for r in per_rank],

@@ -100,6 +100,7 @@ CASES = {
     "embmlp_L32": (dict(latent=32, steps=1, embedding={"mlp": mlp_cfg("leakyrelu", 2)}), "grids", 4, 2, 22),
     "decnorm_L32": (dict(latent=32, steps=1, dec_norm="layer", dec_act="silu"), "random", 4, 2, 23),
     "specnorm_L32": (dict(latent=32, steps=1, dec_spectral=True), "hier", 4, 2, 24),  # decoder spectral_norm (mlp.py:62-63)
+    "L256_s2": (dict(latent=256, steps=2), "hier", 4, 2, 25),  # the upper end of north_star's latent range (64-256)
 }
 
 
