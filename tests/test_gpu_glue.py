@@ -16,7 +16,7 @@ from amber_amd.architecture.supervised_mpn import SupervisedMPN
 from amber_amd.config import AttrDict
 from amber_amd.normalizer import GraphRunningNormalizer
 from amber_amd.prediction_transform import get_transform
-from conftest import glue_cases, load_glue, rel_err
+from conftest import close, glue_cases, load_glue, rel_err
 from oracle import glue_oracle as go
 from oracle import mpn_oracle as orc
 
@@ -154,14 +154,14 @@ def test_fused_predict_matches_oracle_pipeline(gpu_device, name, masked):
     with torch.no_grad():
         got = predict_mod.predict(model, norm, tf, gb, is_train=False)
     want = _oracle_predict(meta, d, cfg, params, g)
-    assert got.shape == want.shape and rel_err(got.cpu(), want) <= 1e-5
+    assert got.shape == want.shape and close(got.cpu(), want)
     assert torch.equal(gb.x, x_before) and torch.equal(gb.edge_attr, e_before)  # the caller's batch is untouched
     # with the inference post-step folded in
     with torch.no_grad():
         got2 = predict_mod.predict(model, norm, tf, gb, clip_min=meta["clip_min"], clip_max=meta["clip_max"],
                                    scale0=meta["scale0"], scale1=meta["scale1"])
     want2 = torch.from_numpy(go.clip_detach_dampen(want, meta["clip_min"], meta["clip_max"], meta["scale0"], meta["scale1"]))
-    assert rel_err(got2.cpu(), want2) <= 1e-5
+    assert close(got2.cpu(), want2)
     # the fused call equals the staged calls of the same library bit for bit
     with torch.no_grad():
         staged = model(syn.GraphBatch(x=glue.normalize_rows(gb.x, d["node_mean"], d["node_var"], meta["epsilon"], meta["input_clip"]),
@@ -181,7 +181,7 @@ def test_training_predict_gradients_match_oracle(gpu_device, name):
     out = predict_mod.predict(model, norm, tf, gb, is_train=True)
     p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
     want = _oracle_predict(meta, d, cfg, p, g, is_train=True)
-    assert rel_err(out.detach().cpu(), want.detach()) <= 1e-5
+    assert close(out.detach().cpu(), want.detach())
     w = torch.randn(want.shape, generator=torch.Generator().manual_seed(1))
     (want * w).sum().backward()
     (out * w.to(gpu_device)).sum().backward()

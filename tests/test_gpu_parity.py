@@ -12,7 +12,7 @@ from amber_amd import engine, synthetic as syn
 from amber_amd.architecture.supervised_mpn import SupervisedMPN
 from amber_amd.config import AttrDict
 from amber_amd.mpn.get_message_passing_base import get_mpn
-from conftest import golden_cases, load_golden, rel_err
+from conftest import close, golden_cases, load_golden, rel_err
 from oracle import mpn_oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -120,9 +120,9 @@ def test_forward_matches_reference_golden(gpu_device, name):
         out = model(batch)
         nodes, edges, bvec = model.mpn(batch)
     assert out.shape == d["out_sizing"].shape
-    assert rel_err(out.cpu(), d["out_sizing"]) <= FP32_TOL
-    assert rel_err(nodes["node"].cpu(), d["out_node"]) <= FP32_TOL
-    assert rel_err(edges["edges"]["edge_attr"].cpu(), d["out_edge"]) <= FP32_TOL
+    assert close(out.cpu(), d["out_sizing"])
+    assert close(nodes["node"].cpu(), d["out_node"])
+    assert close(edges["edges"]["edge_attr"].cpu(), d["out_edge"])
     assert torch.equal(edges["edges"]["edge_index"].cpu(), d["edge_index"])
     assert torch.equal(bvec["node"].cpu(), d["batch"])
     # create_graph_copy=True: the caller's batch is untouched
@@ -139,7 +139,7 @@ def test_forward_without_mask_and_without_batch_vector(gpu_device):
         _, _, bvec = model.mpn(batch)
     want = orc.supervised_mpn_forward(params, cfg, d["x"], d["edge_attr"], d["edge_index"], None)
     assert out.shape == (d["x"].shape[0], 1)
-    assert rel_err(out.cpu(), want) <= FP32_TOL
+    assert close(out.cpu(), want)
     assert torch.equal(bvec["node"], torch.zeros(d["x"].shape[0]).long())  # unpack_features default
 
 
@@ -157,15 +157,15 @@ def test_stage_entry_points_match_oracle(gpu_device, name):
     _, _, steps = orc.mpn_forward(params, cfg, d["x"], d["edge_attr"], d["edge_index"], prefix="mpn.", collect_steps=True)
     x, e = engine.embed(desc, flat, packed, d["x"].to(gpu_device), d["edge_attr"].to(gpu_device), csr)
     perm = csr.perm.long().cpu()
-    assert rel_err(x.cpu(), steps[0][0]) <= FP32_TOL
-    assert rel_err(e.cpu(), steps[0][1][perm]) <= FP32_TOL
+    assert close(x.cpu(), steps[0][0])
+    assert close(e.cpu(), steps[0][1][perm])
     it = 0
     for s in range(cfg["stack"]["num_steps"]):
         for _ in range(cfg["stack"].get("num_step_repeats", 1)):
             engine.block(desc, flat, packed, s, x, e, csr)
             it += 1
-            assert rel_err(x.cpu(), steps[it][0]) <= FP32_TOL, f"node features after block application {it}"
-            assert rel_err(e.cpu(), steps[it][1][perm]) <= FP32_TOL, f"edge features after block application {it}"
+            assert close(x.cpu(), steps[it][0]), f"node features after block application {it}"
+            assert close(e.cpu(), steps[it][1][perm]), f"edge features after block application {it}"
     # head on the oracle's latents
     hdesc = engine.make_desc(has_head=True, decoder_layers=cfg["decoder"]["num_layers"],
                              decoder_activation=cfg["decoder"]["activation_function"],
@@ -176,7 +176,7 @@ def test_stage_entry_points_match_oracle(gpu_device, name):
     got = engine.head(hdesc, hflat, hpacked, steps[-1][0].to(gpu_device).contiguous(), oi, n_out)
     dec = orc.decoder_mlp(params, "decoder_mlp", steps[-1][0][d["mask_output"]], cfg["decoder"], cfg["latent_dimension"])
     want = torch.nn.functional.linear(dec, params["readout.weight"], params["readout.bias"])
-    assert rel_err(got.cpu(), want) <= FP32_TOL
+    assert close(got.cpu(), want)
 
 
 def test_block_and_stack_modules_work_in_place_on_latent_graphs(gpu_device):
@@ -185,11 +185,11 @@ def test_block_and_stack_modules_work_in_place_on_latent_graphs(gpu_device):
     _, _, steps = orc.mpn_forward(params, cfg, d["x"], d["edge_attr"], d["edge_index"], prefix="mpn.", collect_steps=True)
     g = syn.GraphBatch(x=steps[0][0].to(gpu_device), edge_attr=steps[0][1].to(gpu_device), edge_index=d["edge_index"].to(gpu_device))
     model.mpn.message_passing_stack(g)
-    assert rel_err(g.x.cpu(), steps[-1][0]) <= FP32_TOL
-    assert rel_err(g.edge_attr.cpu(), steps[-1][1]) <= FP32_TOL
+    assert close(g.x.cpu(), steps[-1][0])
+    assert close(g.edge_attr.cpu(), steps[-1][1])
     raw = _batch(d, gpu_device)
     model.mpn.input_embeddings(raw)
-    assert rel_err(raw.x.cpu(), steps[0][0]) <= FP32_TOL and rel_err(raw.edge_attr.cpu(), steps[0][1]) <= FP32_TOL
+    assert close(raw.x.cpu(), steps[0][0]) and close(raw.edge_attr.cpu(), steps[0][1])
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -214,7 +214,7 @@ def test_create_graph_copy_false_mutates_and_graph_output_returns_none(gpu_devic
     with torch.no_grad():
         nodes, edges, _ = mpn(g)
     assert g.x.shape == (g.x.shape[0], 32) and g.x is nodes["node"]  # mutated in place, like the reference
-    assert rel_err(g.x.cpu(), wx) <= FP32_TOL and rel_err(g.edge_attr.cpu(), we) <= FP32_TOL
+    assert close(g.x.cpu(), wx) and close(g.edge_attr.cpu(), we)
     mpn2 = get_mpn(in_node_features=4, in_edge_features=2, latent_dimension=32, base_config=_mpn_cfg(), device=gpu_device).eval()
     mpn2._output_type = "graph"
     g2 = syn.grid_batch(num_graphs=1, nx=5, ny=5).to(gpu_device)
@@ -247,7 +247,7 @@ def test_empty_and_ragged_inputs(gpu_device):
     with torch.no_grad():
         nodes, edges, _ = mpn(g)
     wx, we = orc.mpn_forward(sd, cfg, g.x.cpu(), g.edge_attr.cpu(), g.edge_index.cpu())
-    assert edges["edges"]["edge_attr"].shape == (0, 64) and rel_err(nodes["node"].cpu(), wx) <= FP32_TOL
+    assert edges["edges"]["edge_attr"].shape == (0, 64) and close(nodes["node"].cpu(), wx)
     # ragged sizes around the 32-row tile: 1, 31, 32, 33 nodes / edges; one row spanning several tiles
     rng = np.random.default_rng(5)
     for n, e in [(1, 1), (31, 33), (32, 32), (33, 31), (3, 200)]:
@@ -256,8 +256,8 @@ def test_empty_and_ragged_inputs(gpu_device):
         with torch.no_grad():
             nodes, edges, _ = mpn(g)
         wx, we = orc.mpn_forward(sd, cfg, g.x.cpu(), g.edge_attr.cpu(), g.edge_index.cpu())
-        assert rel_err(nodes["node"].cpu(), wx) <= FP32_TOL, (n, e)
-        assert rel_err(edges["edges"]["edge_attr"].cpu(), we) <= FP32_TOL, (n, e)
+        assert close(nodes["node"].cpu(), wx), (n, e)
+        assert close(edges["edges"]["edge_attr"].cpu(), we), (n, e)
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -289,7 +289,7 @@ def test_paper_and_synthetic_shapes_match_oracle(gpu_device, latent, steps, grap
     want = orc.supervised_mpn_forward(sd, cfg, g.x, g.edge_attr, g.edge_index, g.mask_output)
     with torch.no_grad():
         got = model(g.to(gpu_device))
-    assert rel_err(got.cpu(), want) <= FP32_TOL
+    assert close(got.cpu(), want)
 
 
 def test_3d_like_and_hierarchical_graphs_match_oracle(gpu_device):
@@ -298,14 +298,14 @@ def test_3d_like_and_hierarchical_graphs_match_oracle(gpu_device):
     want = orc.supervised_mpn_forward(sd, cfg, g.x, g.edge_attr, g.edge_index, g.mask_output)
     with torch.no_grad():
         got = model(g.to(gpu_device))
-    assert rel_err(got.cpu(), want) <= FP32_TOL
+    assert close(got.cpu(), want)
     rng = np.random.default_rng(9)
     parts = [syn.hierarchical_graph(60, 50, 3, 3, rng), syn.hierarchical_graph(40, 45, 2, 3, rng)]  # hub rows of ~300-500 edges
     g = syn.make_batch([p[0] for p in parts], [p[1] for p in parts], 4, 2, mask_outputs=[p[2] for p in parts])
     want = orc.supervised_mpn_forward(sd, cfg, g.x, g.edge_attr, g.edge_index, g.mask_output)
     with torch.no_grad():
         got = model(g.to(gpu_device))
-    assert got.shape == want.shape and rel_err(got.cpu(), want) <= FP32_TOL
+    assert got.shape == want.shape and close(got.cpu(), want)
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -330,7 +330,7 @@ def test_full_size_batch_properties(gpu_device):
         e0, e1 = int(g.edge_ptr[gi]), int(g.edge_ptr[gi + 1])
         x, ea, ei = g.x[n0:n1], g.edge_attr[e0:e1], g.edge_index[:, e0:e1] - n0
         want = orc.supervised_mpn_forward(sd, cfg, x, ea, ei, None)
-        assert rel_err(out1[n0:n1].cpu(), want) <= FP32_TOL
+        assert close(out1[n0:n1].cpu(), want)
         alone = syn.GraphBatch(x=x, edge_attr=ea, edge_index=ei).to(gpu_device)
         with torch.no_grad():
             got_alone = model(alone)
@@ -354,9 +354,9 @@ def test_batch_beyond_2_31_latent_elements(gpu_device):
         e0, e1 = int(g.edge_ptr[gi]), int(g.edge_ptr[gi + 1])
         ei = g.edge_index[:, e0:e1] - n0
         want = orc.supervised_mpn_forward(sd, cfg, g.x[n0:n1], g.edge_attr[e0:e1], ei, None)
-        assert rel_err(out[n0:n1].cpu(), want) <= FP32_TOL
+        assert close(out[n0:n1].cpu(), want)
         _, we = orc.mpn_forward(sd, cfg, g.x[n0:n1], g.edge_attr[e0:e1], ei, prefix="mpn.")
-        assert rel_err(edges["edges"]["edge_attr"][e0:e1].cpu(), we) <= FP32_TOL  # returned in edge_index order
+        assert close(edges["edges"]["edge_attr"][e0:e1].cpu(), we)  # returned in edge_index order
     del edges
     torch.cuda.empty_cache()
 
@@ -377,4 +377,4 @@ def test_large_batch_properties_other_widths(gpu_device, latent, steps, graphs):
         n0, n1 = int(g.ptr[gi]), int(g.ptr[gi + 1])
         e0, e1 = int(g.edge_ptr[gi]), int(g.edge_ptr[gi + 1])
         want = orc.supervised_mpn_forward(sd, cfg, g.x[n0:n1], g.edge_attr[e0:e1], g.edge_index[:, e0:e1] - n0, None)
-        assert rel_err(out1[n0:n1].cpu(), want) <= FP32_TOL
+        assert close(out1[n0:n1].cpu(), want)

@@ -11,7 +11,7 @@ import pytest
 import torch
 
 from amber_amd import engine, synthetic as syn
-from conftest import golden_cases, load_golden, rel_err
+from conftest import close, golden_cases, load_golden, rel_err
 from oracle import mpn_oracle as orc
 from test_gpu_parity import _batch, _model_from_golden, _supervised
 
@@ -68,8 +68,8 @@ def test_fused_edge_embedding_matches_separate_embedding(gpu_device, fe):
                 separate = model(gd).cpu()
             finally:
                 del os.environ["AMBER_MPN_NO_FUSED_EMBED"]
-        assert rel_err(fused, want) <= FP32_TOL
-        assert rel_err(separate, want) <= FP32_TOL
-        assert rel_err(fused, separate) <= FP32_TOL
+        assert close(fused, want)
+        assert close(separate, want)
+        assert close(fused, separate)
     finally:
         engine.default_precision = old
