@@ -109,6 +109,10 @@ SIGNATURES = {
     "amber_mpn_graph_edge_features": (_I32, [C.POINTER(AmberGraphDesc)]),
     "amber_mpn_build_graph": (C.c_int, [C.POINTER(AmberGraphDesc), _I32, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P, _P, _P, _P, _P]),
     "amber_mpn_build_inter_edges": (C.c_int, [C.POINTER(AmberGraphDesc), _I64, _I64, _I64, _P, _P, _P, _P, _P, _P, _P]),
+    "amber_mpn_project_workspace_bytes": (_SZ, [_I32, _I64, _I64]),
+    "amber_mpn_project_elements_to_vertices": (C.c_int, [_P, _I32, _I64, _I64, _P, _P, _P, _P, _P, _SZ, _P]),
+    "amber_mpn_estimate_workspace_bytes": (_SZ, [_I64, _I64]),
+    "amber_mpn_estimate_num_elements": (C.c_int, [_P, _I32, _I64, _I64, _P, _P, _I32, _I32, _P, _I64, _P, _F64, _P, _P, _SZ, _P]),
     "amber_mpn_predict_workspace_bytes": (_SZ, [_DESC, _I64, _I64]),
     "amber_mpn_predict": (C.c_int, [_DESC, _GLUE, _P, _P, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                     _P, _SZ, _P]),

@@ -1431,4 +1431,55 @@ int amber_mpn_build_inter_edges(const AmberGraphDesc* gdesc, int64_t num_src, in
   return AMBER_OK;
 }
 
+// ---- the step after the model ----
+size_t amber_mpn_project_workspace_bytes(int32_t k, int64_t M, int64_t V) {
+  if (k < 1 || k > 8 || M < 0 || V < 0) return 0;
+  return project_workspace_bytes(k, M, V) + 256;
+}
+
+int amber_mpn_project_elements_to_vertices(const int64_t* simplices, int32_t k, int64_t M, int64_t V, const double* element_values,
+                                           const double* volumes, double* out, int32_t* status, void* workspace,
+                                           size_t workspace_bytes, void* stream) {
+  if (k < 1 || k > 8) return fail(AMBER_ERR_UNSUPPORTED, "verts_per_element %d not in 1..8", k);
+  if (M < 0 || V < 0 || static_cast<int64_t>(k) * M >= (1ll << 31) || V >= (1ll << 31))
+    return fail(AMBER_ERR_INVALID_ARGUMENT, "sizes out of int32 range");
+  if (!status || !workspace) return fail(AMBER_ERR_INVALID_ARGUMENT, "status / workspace is NULL");
+  if (M > 0 && (!simplices || !element_values || !volumes)) return fail(AMBER_ERR_INVALID_ARGUMENT, "element arrays are NULL");
+  if (M > 0 && V == 0) return fail(AMBER_ERR_INVALID_ARGUMENT, "elements without vertices");
+  if (V > 0 && !out) return fail(AMBER_ERR_INVALID_ARGUMENT, "out is NULL");
+  if (workspace_bytes < amber_mpn_project_workspace_bytes(k, M, V))
+    return fail(AMBER_ERR_WORKSPACE_TOO_SMALL, "workspace %zu < %zu bytes", workspace_bytes, amber_mpn_project_workspace_bytes(k, M, V));
+  (void)hipGetLastError();
+  HIP_TRY(launch_project_elements(simplices, k, M, V, element_values, volumes, out, status, aligned_ws(workspace),
+                                  static_cast<hipStream_t>(stream)),
+          "project_elements_to_vertices");
+  return AMBER_OK;
+}
+
+size_t amber_mpn_estimate_workspace_bytes(int64_t V, int64_t Me) {
+  if (V < 0 || Me < 0) return 0;
+  return estimate_workspace_bytes(V, Me) + 256;
+}
+
+int amber_mpn_estimate_num_elements(const int64_t* simplices, int32_t k, int64_t M, int64_t V, const double* volumes,
+                                    const double* sizing_field, int32_t vertex_field, int32_t dim, const int64_t* edges, int64_t Me,
+                                    const double* positions, double gradation, double* out, void* workspace, size_t workspace_bytes,
+                                    void* stream) {
+  if (dim != 2 && dim != 3) return fail(AMBER_ERR_UNSUPPORTED, "Dimension %d not supported", dim);
+  if (k < 1 || k > 8 || M < 0 || V < 0 || Me < 0) return fail(AMBER_ERR_INVALID_ARGUMENT, "bad sizes");
+  if (!out || !workspace) return fail(AMBER_ERR_INVALID_ARGUMENT, "out / workspace is NULL");
+  if (M > 0 && (!volumes || !sizing_field)) return fail(AMBER_ERR_INVALID_ARGUMENT, "volumes / sizing_field is NULL");
+  if (vertex_field) {
+    if (M > 0 && !simplices) return fail(AMBER_ERR_INVALID_ARGUMENT, "simplices is NULL");
+    if (V > 0 && !sizing_field) return fail(AMBER_ERR_INVALID_ARGUMENT, "sizing_field is NULL");
+    if (Me > 0 && (!edges || !positions)) return fail(AMBER_ERR_INVALID_ARGUMENT, "edges / positions is NULL");
+  }
+  if (workspace_bytes < amber_mpn_estimate_workspace_bytes(V, Me)) return fail(AMBER_ERR_WORKSPACE_TOO_SMALL, "workspace too small");
+  (void)hipGetLastError();
+  HIP_TRY(launch_estimate_elements(simplices, k, M, V, volumes, sizing_field, vertex_field ? 1 : 0, dim, edges, vertex_field ? Me : 0,
+                                   positions, gradation, out, aligned_ws(workspace), static_cast<hipStream_t>(stream)),
+          "estimate_num_elements");
+  return AMBER_OK;
+}
+
 }  // extern "C"

@@ -269,6 +269,15 @@ hipError_t launch_build_graph(const GraphArgs& a, hipStream_t s);
 hipError_t launch_inter_edges(const GraphArgs& a, const int64_t* nearest, const double* pos_src, const double* pos_dst, int64_t n_src,
                               int64_t n_dst, int64_t index_offset, hipStream_t s);
 
+// ---- the step after the model: element -> vertex projection, element-count estimate (mesh.hip) ----
+size_t project_workspace_bytes(int k, int64_t M, int64_t V);
+hipError_t launch_project_elements(const int64_t* t, int k, int64_t M, int64_t V, const double* val, const double* vol, double* out,
+                                   int32_t* status, void* ws, hipStream_t s);
+size_t estimate_workspace_bytes(int64_t V, int64_t Me);
+hipError_t launch_estimate_elements(const int64_t* t, int k, int64_t M, int64_t V, const double* vol, const double* field,
+                                    int vertex_field, int dim, const int64_t* edges, int64_t Me, const double* pos,
+                                    double gradation, double* out, void* ws, hipStream_t s);
+
 size_t csr_workspace_bytes(int64_t N, int64_t E);
 hipError_t csr_build(const int64_t* edge_index, int64_t E, int64_t N, int32_t* rowptr, int32_t* src_sorted,
                      int32_t* dst_sorted, int32_t* perm, int32_t* status, void* ws, hipStream_t s);

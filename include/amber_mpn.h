@@ -346,6 +346,34 @@ int amber_mpn_build_inter_edges(const AmberGraphDesc* gdesc, int64_t num_src, in
                                 const int64_t* nearest, const double* pos_src, const double* pos_dst, int64_t* edge_index,
                                 float* edge_attr, int32_t* status, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------
+ * The step after the model, in float64 as the reference computes it.  A simplicial mesh is
+ * given as skfem holds it: simplices t [k, M] int64 (k = dim + 1 vertex ids per element, row-major: mesh.t), per-element
+ * volumes [M] (mesh.simplex_volumes).
+ *
+ * amber_mpn_project_elements_to_vertices: volume-weighted mean of the values of the elements around every vertex
+ * (project_elements_to_vertices, src/mesh_util/sizing_field_util.py:43-70: two torch_scatter.scatter_add over
+ * mesh.t.T.flatten()).  Every vertex adds its entries in that list's order (the stable CSR sort of amber_mpn_csr_build),
+ * so sums and quotient are BIT-IDENTICAL to the reference's; a vertex without elements gives nan (0 / 0), as there.
+ * status: int32[1], 1 if a vertex id lies outside [0, num_vertices) (clamped).
+ *
+ * amber_mpn_estimate_num_elements: the heuristic element count of the mesh a sizing field would produce
+ * (_mesh_sizing_field_to_num_elements, sizing_field_util.py:128-200).  vertex_field = 1: sizing_field [V] on the vertices,
+ * smoothed by two gradation passes over the mesh edges (edges [2, Me] int64 = mesh.mesh_edges, positions [V, dim] float64;
+ * np.maximum.at becomes an order-independent atomic maximum), averaged per element, times 0.618 in 3D; vertex_field = 0:
+ * sizing_field [M] on the elements (edges / positions unused).  out: float64[1] on the device.  Equal to the reference
+ * within 1e-12 relative (pow and the order of the final sum differ in the last bits).
+ * ------------------------------------------------------------------------------------------------- */
+size_t amber_mpn_project_workspace_bytes(int32_t verts_per_element, int64_t num_elements, int64_t num_vertices);
+int amber_mpn_project_elements_to_vertices(const int64_t* simplices, int32_t verts_per_element, int64_t num_elements,
+                                           int64_t num_vertices, const double* element_values, const double* volumes, double* out,
+                                           int32_t* status, void* workspace, size_t workspace_bytes, void* stream);
+size_t amber_mpn_estimate_workspace_bytes(int64_t num_vertices, int64_t num_mesh_edges);
+int amber_mpn_estimate_num_elements(const int64_t* simplices, int32_t verts_per_element, int64_t num_elements, int64_t num_vertices,
+                                    const double* volumes, const double* sizing_field, int32_t vertex_field, int32_t dim,
+                                    const int64_t* edges, int64_t num_mesh_edges, const double* positions, double gradation,
+                                    double* out, void* workspace, size_t workspace_bytes, void* stream);
+
 int amber_mpn_abi_version(void);
 const char* amber_mpn_last_error(void);
 

@@ -18,7 +18,7 @@ def pytest_configure(config):
 
 
 def golden_cases():
-    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and not f.startswith(("glue_", "graph_")))
+    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and not f.startswith(("glue_", "graph_", "mesh_")))
 
 
 def glue_cases():
@@ -32,6 +32,16 @@ def graph_cases():
 def hier_cases():
     """Fixtures of the hierarchical observation graph (inter-level edges), load with load_graph(name)."""
     return sorted(f[6:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and f.startswith("graph_hier_"))
+
+
+def mesh_cases():
+    return sorted(f[5:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and f.startswith("mesh_"))
+
+
+def load_mesh(name):
+    """One fixture of the step after the model (tests/golden/make_golden_mesh.py): (meta dict, {name: ndarray})."""
+    z = np.load(os.path.join(GOLDEN_DIR, f"mesh_{name}.npz"), allow_pickle=False)
+    return json.loads(str(z["meta"])), {k: z[k] for k in z.files if k != "meta"}
 
 
 def load_graph(name):
