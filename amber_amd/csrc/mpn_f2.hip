@@ -1049,6 +1049,7 @@ __global__ __launch_bounds__(64 * node_waves<L>()) void node_kernel_f2(const Nod
       }
       Tile<L> acc;
       float scale, inv;
+      ELanding<L> lg;  // whole row pieces of the aggregate
       {
         // ---- whole row pieces of x ----
         ELanding<L> lx;
@@ -1065,22 +1066,36 @@ __global__ __launch_bounds__(64 * node_waves<L>()) void node_kernel_f2(const Nod
         tile_zero<L>(acc);  // the first MFMAs take the constant 0 as C; the bias joins the final rescale
         const unsigned char* wl = begin_phase(k++);
         STAMP(2);  // barrier
-        if (!DBG(256)) gemm_rows<L, SPLIT, true>(acc, lx, scale, win, wo, wl, lane);
+#ifndef AMBER_NODE_NO_PREFETCH_AGG
+        // The rows of sums (agg, or the tail slot when a reduction tile's border cut the row) are fetched under THIS
+        // contraction: every pass leaves a quarter of x's landing registers, and that quarter of the aggregate's pieces is
+        // loaded into them at once - the waves of a workgroup walk the phases together, so nothing else would cover the
+        // latency of these loads (10 k of a tile's 102 k cycles when they were issued after the phase).
+        if (!DBG(256))
+          gemm_rows<L, SPLIT, true>(acc, lx, scale, win, wo, wl, lane, [&](int ps) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+              const float* src = tl[it] != tf[it] ? a.tail + static_cast<int64_t>(tf[it]) * L : a.agg + nd[it] * L;
+              lg.v[ps][it] = (reinterpret_cast<const f32x4*>(src) + (lq & 7))[ps * 8];
+            }
+          });
+        else
+#endif
+        {
+          if (!DBG(256)) gemm_rows<L, SPLIT, true>(acc, lx, scale, win, wo, wl, lane);
+#pragma unroll
+          for (int it = 0; it < 4; ++it) {
+            const float* src = tl[it] != tf[it] ? a.tail + static_cast<int64_t>(tf[it]) * L : a.agg + nd[it] * L;
+            const f32x4* pg = reinterpret_cast<const f32x4*>(src) + (lq & 7);
+#pragma unroll
+            for (int ps = 0; ps < NFB; ++ps) lg.v[ps][it] = pg[ps * 8];
+          }
+        }
         STAMP(3);  // W0x
       }
       {
-        // ---- whole row pieces of the aggregate: sums of the edge kernel -> mean ----
-        ELanding<L> lg;
-        // Three rounds of loads, each issued for all four row pieces of the lane before any is used: rowptr; the row
-        // of sums (agg, or the tail slot when tile boundaries of the edge kernel cut the row); the first head slot of
-        // a cut row.  Rows cut more than once (longer than a tile) add their further heads in a loop.
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-          const float* src = tl[it] != tf[it] ? a.tail + static_cast<int64_t>(tf[it]) * L : a.agg + nd[it] * L;
-          const f32x4* pg = reinterpret_cast<const f32x4*>(src) + (lq & 7);
-#pragma unroll
-          for (int ps = 0; ps < NFB; ++ps) lg.v[ps][it] = pg[ps * 8];
-        }
+        // ---- whole row pieces of the aggregate: sums of the edge kernel -> mean.  After the row of sums: the first
+        // head slot of a cut row; rows cut more than once (longer than a reduction tile) add their further heads in a loop.
         {
           ELanding<L> hd;
 #pragma unroll
