@@ -128,8 +128,11 @@ def eager_gpu_baseline(cfg, state_dict, g, dev):
                       f"peak allocated {peak:.0f} GiB"}
 
 
-def measured_traffic():
-    """(bytes per edge-kernel launch from the PMC passes | None, note)."""
+def measured_traffic(latent: int, edges: int):
+    """(bytes per edge-kernel launch from the PMC passes | None, note).  The counters were collected on the headline
+    workload (config 5: latent 128, E = 9,984,200); any other workload reports None."""
+    if latent != 128 or edges != 9984200:
+        return None, "PMC traffic is measured on the headline workload only (tools/profile_round.sh)"
     tpath = os.path.join(REPO, "profiles", "traffic.json")
     if not os.path.exists(tpath):
         return None, "no profiles/traffic.json"
@@ -358,7 +361,7 @@ def main():
         flops_useful = e * 4.0 * L * L
         ach_gbs = bytes_per_launch / (edge_ms * 1e-3) / 1e9
         ach_tf_exec = 3.0 * flops_useful / (edge_ms * 1e-3) / 1e12
-        traffic, traffic_note = measured_traffic()
+        traffic, traffic_note = measured_traffic(L, e)
         split = engine.default_precision != "fp32" and L <= 128  # the split-precision kernels ran (else: exact fp32 MFMA)
         if split:
             roofline = {"kernel": f"edge_kernel_f2<{L}>", "bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
