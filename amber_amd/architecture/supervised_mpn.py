@@ -97,8 +97,8 @@ class SupervisedMPN(nn.Module):
         dec = self.decoder_mlp
         desc, base, dec_pieces, dec_sources, tail = self._plan(single_row=(n_out == 1))
         if engine.wants_grad(base + dec_sources + tail):  # training step (src/algorithm/core/amber.py:62-82)
-            if dec.latent_normalization is not None:
-                raise NotImplementedError("amber_amd: decoder latent_normalization is not built for training")
+            if dec.latent_normalization == "batch":
+                raise NotImplementedError("amber_amd: decoder BatchNorm is not built for training (latent_normalization none / layer are)")
             return engine.MpnFunction.apply(desc, self._packed, observations.x, observations.edge_attr, csr, out_index, n_out,
                                             False, False, base + dec_sources + tail, *(base + dec_pieces + tail))[2]
         flat, packed = self._packed.get(desc, base + dec_pieces + tail, key_tensors=base + dec_sources + tail

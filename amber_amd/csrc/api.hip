@@ -206,11 +206,14 @@ Workspace carve(const AmberMpnDesc& d, int64_t N, int64_t E, void* base) {
   return w;
 }
 
-// training tape: block inputs of every step, x_t[N,L] and e_t[E,L] (CSR order), t = 0 .. iters
+// training tape: block inputs of every step, x_t[N,L] and e_t[E,L] (CSR order), t = 0 .. iters; with an "outer" residual /
+// LayerNorm also the mean aggregate m_t[N,L] of every step (the node module aggregates the edge module's output BEFORE the
+// outer residual / LayerNorm, which is not the e_{t+1} of the tape)
 struct Tape {
-  float *x, *e;
+  float *x, *e, *m;
   size_t bytes;
 };
+bool has_outer_mode(const AmberMpnDesc& d) { return d.residual == AMBER_MODE_OUTER || d.layer_norm == AMBER_MODE_OUTER; }
 Tape carve_tape(const AmberMpnDesc& d, int64_t N, int64_t E, float* base) {
   const size_t L = static_cast<size_t>(d.latent), T1 = static_cast<size_t>(d.num_steps) * d.num_step_repeats + 1;
   Tape t;
@@ -218,6 +221,11 @@ Tape carve_tape(const AmberMpnDesc& d, int64_t N, int64_t E, float* base) {
   const size_t xb = align256(sizeof(float) * T1 * static_cast<size_t>(N) * L);
   t.e = reinterpret_cast<float*>(reinterpret_cast<char*>(base) + xb);
   t.bytes = xb + align256(sizeof(float) * T1 * static_cast<size_t>(E) * L);
+  t.m = nullptr;
+  if (has_outer_mode(d)) {
+    t.m = reinterpret_cast<float*>(reinterpret_cast<char*>(base) + t.bytes);
+    t.bytes += align256(sizeof(float) * (T1 - 1) * static_cast<size_t>(N) * L);
+  }
   return t;
 }
 
@@ -534,6 +542,10 @@ int forward_impl(const AmberMpnDesc* desc, const float* params, const float* pac
     hipError_t e = run_edge(d, ea, s);
     tm.end();
     HIP_TRY(e, "edge kernel");
+    if (tape && tp.m)
+      HIP_TRY(launch_partials_mean(w.agg, w.head, w.tail, rowptr, use_fast_edge(d) ? 4 : 5, N, L,
+                                   tp.m + static_cast<size_t>(it) * N * L, s),
+              "mean aggregate for the tape");
 
     NodeArgs na{};
     na.N = N;
@@ -570,13 +582,11 @@ int forward_impl(const AmberMpnDesc* desc, const float* params, const float* pac
 // ---------------------------------------------------------------------------------------------------
 int validate_train(const AmberMpnDesc& d) {
   if (d.latent > 128) return fail(AMBER_ERR_UNSUPPORTED, "training: latent_dimension %d is not built (32, 64, 128 are)", d.latent);
-  if (d.residual == AMBER_MODE_OUTER || d.layer_norm == AMBER_MODE_OUTER)
-    return fail(AMBER_ERR_UNSUPPORTED, "training: 'outer' residual / layer_norm is not built (inner and none are)");
-  if (d.embed_layers > 0) return fail(AMBER_ERR_UNSUPPORTED, "training: MLP input embeddings are not built (linear / constant are)");
   if (d.has_head) {
     if (d.decoder_activation > AMBER_ACT_TANH)
       return fail(AMBER_ERR_UNSUPPORTED, "training: decoder activation id %d (relu, leakyrelu, tanh only)", d.decoder_activation);
-    if (d.decoder_norm != AMBER_NORM_NONE) return fail(AMBER_ERR_UNSUPPORTED, "training: decoder latent_normalization is not built");
+    if (d.decoder_norm != AMBER_NORM_NONE && d.decoder_norm != AMBER_NORM_LAYER)
+      return fail(AMBER_ERR_UNSUPPORTED, "training: decoder BatchNorm is not built (latent_normalization none / layer are)");
   }
   return AMBER_OK;
 }
@@ -587,7 +597,8 @@ struct BwdWorkspace {
   float* DHN[kMaxLayers];
   float* AE[kMaxLayers];
   float* DHE[kMaxLayers];
-  float *gpart, *cpart, *lnpart, *epart, *mats;
+  float* APN[kMaxLayers];  // decoder LayerNorm: activations before the norm
+  float *gpart, *cpart, *lnpart, *pnpart, *epart, *mats;
   size_t mat_floats;
   size_t bytes;
 };
@@ -611,19 +622,25 @@ BwdWorkspace carve_bwd(const AmberMpnDesc& d, int64_t N, int64_t E, void* base) 
   w.Pd = take(nb);
   w.dPs = take(nb);
   w.dPd = take(nb);
-  const int nn = d.mlp_layers > d.decoder_layers ? d.mlp_layers : d.decoder_layers;
+  // row buffers per layer: the stack's MLPs, the decoder (node rows) and the embedding MLPs' tails (their a_0 sits in the
+  // last slot, see backward_impl)
+  const int ne = d.mlp_layers > d.embed_layers ? d.mlp_layers : d.embed_layers;
+  const int nn = ne > d.decoder_layers ? ne : d.decoder_layers;
+  const bool dnorm = d.has_head && d.decoder_norm == AMBER_NORM_LAYER;
   for (int l = 0; l < kMaxLayers; ++l) {
     w.AN[l] = l < nn ? take(nb) : nullptr;
     w.DHN[l] = l < nn ? take(nb) : nullptr;
+    w.APN[l] = dnorm && l < d.decoder_layers ? take(nb) : nullptr;
   }
   w.dE = take(eb);
   for (int l = 0; l < kMaxLayers; ++l) {
-    w.AE[l] = l < d.mlp_layers ? take(eb) : nullptr;
-    w.DHE[l] = l < d.mlp_layers ? take(eb) : nullptr;
+    w.AE[l] = l < ne ? take(eb) : nullptr;
+    w.DHE[l] = l < ne ? take(eb) : nullptr;
   }
   w.gpart = take(align256(sizeof(float) * kWgradMaxChunks * L * L));
   w.cpart = take(align256(sizeof(float) * kWgradMaxChunks * L));
   w.lnpart = take(align256(sizeof(float) * kBwdMaxBlocks * 2 * L));
+  w.pnpart = dnorm ? take(align256(sizeof(float) * kBwdMaxBlocks * kBwdWavesPerBlock * d.decoder_layers * 2 * L)) : nullptr;
   w.epart = take(align256(sizeof(float) * kWgradMaxChunks * L * 65));
   w.mat_floats = L * L + kPackedHeader;
   w.mats = take(align256(sizeof(float) * kBwdMats * w.mat_floats));
@@ -688,6 +705,18 @@ int backward_impl(const AmberMpnDesc* desc, const float* params, const float* pa
       a.A[l] = w.AN[l];
       a.DH[l] = w.DHN[l];
     }
+    const bool dnorm = d.decoder_norm == AMBER_NORM_LAYER && nd > 0;
+    const int gwaves = gn * kBwdWavesPerBlock;
+    if (dnorm) {  // mlp.py:86-93: a LayerNorm behind every layer's activation (torch's default eps, as the forward)
+      a.eps = 1e-5f;
+      for (int l = 0; l < nd; ++l) {
+        a.pn_gamma[l] = params + lay.dec.P[l];
+        a.pn_beta[l] = params + lay.dec.Q[l];
+        a.AP[l] = w.APN[l];
+      }
+      a.pn_part = w.pnpart;
+      HIP_TRY(hipMemsetAsync(w.pnpart, 0, sizeof(float) * static_cast<size_t>(gwaves) * nd * 2 * L, s), "clear decoder LayerNorm partials");
+    }
     a.dio = w.dX;
     a.dout = grad_sizing;
     a.out_index = out_index;
@@ -695,6 +724,11 @@ int backward_impl(const AmberMpnDesc* desc, const float* params, const float* pa
     a.part = w.lnpart;
     HIP_TRY(launch_chain_bwd(L, a, s), "head backward kernel");
     HIP_TRY(launch_colpart_reduce(w.lnpart, gn, L, g + lay.readout_w, L, g + lay.readout_b, 1, s), "readout gradient");
+    if (dnorm)
+      for (int l = 0; l < nd; ++l)
+        HIP_TRY(launch_colpart_reduce_strided(w.pnpart + static_cast<size_t>(l) * 2 * L, gwaves, static_cast<int64_t>(nd) * 2 * L, L,
+                                              g + lay.dec.P[l], g + lay.dec.Q[l], s),
+                "decoder LayerNorm gradient");
     for (int l = 0; l < nd; ++l)
       HIP_TRY(launch_wgrad(L, w.DHN[l], l == 0 ? xbuf(iters) : w.AN[l - 1], N, g + lay.dec.W[l], L, 0, g + lay.dec.B[l], w.gpart,
                            w.cpart, s),
@@ -711,7 +745,7 @@ int backward_impl(const AmberMpnDesc* desc, const float* params, const float* pa
     const MlpLayout& me = lay.edge[step];
     const float* x_in = xbuf(it);
     const float* e_in = ebuf(it);
-    const bool ln = d.layer_norm == AMBER_MODE_INNER;
+    const bool ln = d.layer_norm != AMBER_MODE_NONE;
     // ---- the step's matrices in the exact operand order, plain and transposed: one launch ----
     // slots: node W0x 0/1, W0a 2/3, W_l 2+2l / 3+2l;  edge W0e 12/13, W_l 12+2l / 13+2l;  W0s^T 20, W0d^T 21
     {
@@ -742,7 +776,10 @@ int backward_impl(const AmberMpnDesc* desc, const float* params, const float* pa
       }
     }
     // ---- node module: x' = LN(MLP([x, mean(e')]) + x) ----
-    if (E > 0)
+    const float* mean_in = w.M;
+    if (tp.m)  // outer modes: the aggregate of the edge module's output before the outer residual / LayerNorm, kept by the forward
+      mean_in = tp.m + static_cast<size_t>(it) * NL;
+    else if (E > 0)
       HIP_TRY(launch_segment_reduce(ebuf(it + 1), rowptr, nullptr, N, L, 1, w.M, s), "mean aggregate");
     else
       HIP_TRY(hipMemsetAsync(w.M, 0, sizeof(float) * NL, s), "clear M");
@@ -751,11 +788,13 @@ int backward_impl(const AmberMpnDesc* desc, const float* params, const float* pa
       a.mode = AMBER_BWD_NODE;
       a.rows = N;
       a.rin = x_in;
-      a.m = w.M;
+      a.m = mean_in;
       a.nl = nl;
       a.act = d.activation;
-      a.residual = d.residual;
-      a.layer_norm = d.layer_norm;
+      // node rows have one consumer, so "outer" only differs from "inner" for residual outer + LayerNorm inner
+      // (y = LN(m) + x); every other combination is one of the inner forms (message_passing_block.py:124-128)
+      a.residual = d.residual == AMBER_MODE_OUTER ? (d.layer_norm == AMBER_MODE_INNER ? AMBER_MODE_OUTER : AMBER_MODE_INNER) : d.residual;
+      a.layer_norm = ln ? AMBER_MODE_INNER : AMBER_MODE_NONE;
       a.gamma = ln ? params + lay.ng[step] : nullptr;
       a.eps = d.ln_eps;
       a.w_in = mat(0);
@@ -779,7 +818,7 @@ int backward_impl(const AmberMpnDesc* desc, const float* params, const float* pa
       WgradBatch wb{};
       wb.M = N;
       wjob(wb, w.DHN[0], x_in, g + mn.W[0], 2 * L, 0, g + mn.B[0]);  // dW0x, db0
-      wjob(wb, w.DHN[0], w.M, g + mn.W[0], 2 * L, L, nullptr);       // dW0a
+      wjob(wb, w.DHN[0], mean_in, g + mn.W[0], 2 * L, L, nullptr);   // dW0a
       for (int l = 1; l < nl; ++l) wjob(wb, w.DHN[l], w.AN[l - 1], g + mn.W[l], L, 0, g + mn.B[l]);
       HIP_TRY(launch_wgrad_batch(L, wb, w.gpart, w.cpart, s), "node weight gradients");
     }
@@ -837,17 +876,66 @@ int backward_impl(const AmberMpnDesc* desc, const float* params, const float* pa
       HIP_TRY(launch_rows_gemm_add(L, w.dX, w.dPs, mat(20), w.dPd, mat(21), N, s), "dx from the projections");
     }
   }
-  // ---- input embeddings (src/mpn/input_embedding.py:41-42) ----
-  {
-    const MlpLayout& m = lay.node_embed;
-    const int F = d.in_node_features;
-    HIP_TRY(launch_embed_bwd(L, w.dX, x, nullptr, N, F, F > 0 ? g + m.W[0] : nullptr, g + m.B[0], w.epart, s), "node embedding gradient");
-  }
+  // ---- input embeddings (src/mpn/input_embedding.py:41-42; Embedding.forward, src/mpn/common/embedding.py:44-54) ----
+  // linear / constant: d W = d^T raw, d b = column sums.  LatentMLP (embed_layers = K >= 1): a_0 = act(W_0 raw + b_0),
+  // a_l = act(W_l a_{l-1} + b_l); the tail l >= 1 is a dense chain (chain kernel, node mode without an aggregate) on a
+  // recomputed a_0, then act' of layer 0 and the raw-feature product.
+  auto embedding_bwd = [&](const MlpLayout& m, int F, const float* raw, const int32_t* rperm, int64_t rows, float* dio,
+                           float* const* A, float* const* DH, const float* out0) -> int {
+    const int K = d.embed_layers;
+    if (F == 0 || K == 0) {
+      HIP_TRY(launch_embed_bwd(L, dio, raw, rperm, rows, F, F > 0 ? g + m.W[0] : nullptr, g + m.B[0], w.epart, s), "embedding gradient");
+      return AMBER_OK;
+    }
+    const float* a0 = out0;  // K == 1: the embedding's output is a_0
+    if (K > 1) {
+      float* a0buf = A[K - 1];
+      HIP_TRY(launch_embed(L, raw, rows, F, params + m.W[0], params + m.B[0], rperm, d.embed_activation, a0buf, s), "embedding recompute");
+      a0 = a0buf;
+      PackBatch pb{};
+      for (int l = 1; l < K; ++l) {
+        pb.job[pb.n++] = PackJob{params + m.W[l], mat(2 * (l - 1)), L, 0, 0};
+        pb.job[pb.n++] = PackJob{params + m.W[l], mat(2 * (l - 1) + 1), L, 0, 1};
+      }
+      HIP_TRY(launch_pack_batch(L, pb, s), "pack embedding matrices");
+      ChainBwdArgs a{};
+      a.mode = AMBER_BWD_NODE;
+      a.rows = rows;
+      a.rin = a0;
+      a.m = nullptr;  // no aggregate: a plain dense chain
+      a.nl = K - 1;
+      a.act = d.embed_activation;
+      a.residual = AMBER_MODE_NONE;
+      a.layer_norm = AMBER_MODE_NONE;
+      a.eps = d.ln_eps;
+      a.w_in = mat(0);
+      a.wT_in = mat(1);
+      a.b0 = params + m.B[1];
+      for (int l = 1; l < K - 1; ++l) {
+        a.layers[l] = DenseLayer{mat(2 * l), params + m.B[l + 1], nullptr, nullptr};
+        a.wT[l] = mat(2 * l + 1);
+      }
+      for (int l = 0; l < K - 1; ++l) {
+        a.A[l] = A[l];
+        a.DH[l] = DH[l];
+      }
+      a.dio = dio;
+      HIP_TRY(launch_chain_bwd(L, a, s), "embedding MLP backward kernel");
+      WgradBatch wb{};
+      wb.M = rows;
+      wjob(wb, DH[0], a0, g + m.W[1], L, 0, g + m.B[1]);
+      for (int l = 1; l < K - 1; ++l) wjob(wb, DH[l], A[l - 1], g + m.W[l + 1], L, 0, g + m.B[l + 1]);
+      HIP_TRY(launch_wgrad_batch(L, wb, w.gpart, w.cpart, s), "embedding MLP weight gradients");
+    }
+    HIP_TRY(launch_mul_dact(dio, a0, rows * L, d.embed_activation, s), "embedding activation gradient");
+    HIP_TRY(launch_embed_bwd(L, dio, raw, rperm, rows, F, g + m.W[0], g + m.B[0], w.epart, s), "embedding gradient");
+    return AMBER_OK;
+  };
+  int rc = embedding_bwd(lay.node_embed, d.in_node_features, x, nullptr, N, w.dX, w.AN, w.DHN, xbuf(0));
+  if (rc) return rc;
   if (E > 0) {
-    const MlpLayout& m = lay.edge_embed;
-    const int F = d.in_edge_features;
-    HIP_TRY(launch_embed_bwd(L, w.dE, edge_attr, perm, E, F, F > 0 ? g + m.W[0] : nullptr, g + m.B[0], w.epart, s),
-            "edge embedding gradient");
+    rc = embedding_bwd(lay.edge_embed, d.in_edge_features, edge_attr, perm, E, w.dE, w.AE, w.DHE, ebuf(0));
+    if (rc) return rc;
   }
   return AMBER_OK;
 }

@@ -20,6 +20,8 @@
 
 namespace amber {
 
+static_assert(kBwdWavesPerBlock == kWavesPerBlock, "pn_part is sized by kBwdWavesPerBlock");
+
 // ---------------------------------------------------------------------------------------------------
 // wave-local tile helpers (no workgroup barrier: every wave walks its own tiles)
 // ---------------------------------------------------------------------------------------------------
@@ -155,8 +157,19 @@ DEVINL void wave_global_handover() {
 //   mode NODE: rows = nodes; h0 = b0 + W0x x + W0a m;                       dy = dX;  also DM = W0a^T dh0
 //   mode HEAD: rows = nodes; decoder chain on x, out = wr . a_last + br;    dy = dout[out_index] * wr
 // then a_l = act(W_l a_{l-1} + b_l), r = a_last (+ rin), y = LayerNorm(r) (inner modes).
+// EXT = true is a second instantiation for the configurations beside AMBER's default (the default's code generation stays
+// what it was):
+//   * "outer" residual / LayerNorm (message_passing_block.py:91-97): the module's output that the node module aggregates
+//     (e_mid) is not the block's output e_out = [LN](e_mid [+ e]); the gradient from the aggregate joins at e_mid, after
+//     the outer LayerNorm's backward.  Node rows have no second consumer, so the host folds their outer modes into the
+//     inner forms except residual outer + LayerNorm inner: y = LN(m) + x.
+//   * mode NODE without an aggregate (a.m == nullptr): a plain dense chain - the tail of a LatentMLP input embedding
+//     (src/mpn/common/embedding.py:35-38).
+//   * mode HEAD with a LayerNorm behind every decoder layer (mlp.py:86-93, latent_normalization "layer"): a_l is kept in
+//     AP[l], the next layer reads n_l = LN_l(a_l); the (d gamma_l, d beta_l) column sums are added per wave into
+//     pn_part[wave][l][2][L] (every wave owns its slots: no atomics, fixed order).
 // ---------------------------------------------------------------------------------------------------
-template <int L>
+template <int L, bool EXT>
 __global__ __launch_bounds__(kBlock, L <= 64 ? 2 : 1) void chain_bwd_kernel(const ChainBwdArgs a, const int64_t ntiles) {
   __shared__ __attribute__((aligned(16))) float stage_all[kWavesPerBlock * stage_floats<L>()];
   const int lane0 = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -184,6 +197,14 @@ __global__ __launch_bounds__(kBlock, L <= 64 ? 2 : 1) void chain_bwd_kernel(cons
     int64_t p = p0 + c;
     if (p > a.rows - 1) p = a.rows - 1;  // rows beyond the end repeat the last row; their gradient is zeroed below
     const bool rowok = c < nvalid;
+    bool ln_outer = false, has_m = a.mode == AMBER_BWD_NODE, dnorm = false;
+    if constexpr (EXT) {
+      ln_outer = a.layer_norm == AMBER_MODE_OUTER;
+      has_m = has_m && a.m != nullptr;
+      dnorm = a.mode == AMBER_BWD_HEAD && a.pn_gamma[0] != nullptr;
+    }
+    // is the residual term inside the LayerNorm's input?  (outer LayerNorm: whenever there is a residual at all)
+    const bool res_in_ln = ln_outer ? a.residual != AMBER_MODE_NONE : a.residual == AMBER_MODE_INNER;
 
     // ---- recompute the forward chain (tiles that are needed again later are re-read, not kept: registers) ----
     Tile<L> cur;
@@ -203,7 +224,7 @@ __global__ __launch_bounds__(kBlock, L <= 64 ? 2 : 1) void chain_bwd_kernel(cons
         } else {
           tile_load_vec<L>(cur, a.b0, h);
           tile_gemm_lean<L>(cur, a.w_in, rin, lane);
-          if (a.mode == AMBER_BWD_NODE) {
+          if (has_m) {
             tile_load_row<L>(rin, a.m, p, h);
             tile_gemm_lean<L>(cur, a.w_m, rin, lane);
           }
@@ -212,6 +233,12 @@ __global__ __launch_bounds__(kBlock, L <= 64 ? 2 : 1) void chain_bwd_kernel(cons
     }
     if (a.nl > 0) {
       tile_act_w<L>(cur, a.act, stage, lane);
+      if constexpr (EXT) {
+        if (dnorm) {
+          tile_store_w<L>(stage, cur, a.AP[0], p0, nvalid, lane);
+          tile_layernorm<L>(cur, a.pn_gamma[0], a.pn_beta[0], a.eps, h);
+        }
+      }
 #pragma unroll 1
       for (int l = 1; l < a.nl; ++l) {
         tile_store_w<L>(stage, cur, a.A[l - 1], p0, nvalid, lane);  // input of layer l: needed by dW_l and by act' below
@@ -220,16 +247,24 @@ __global__ __launch_bounds__(kBlock, L <= 64 ? 2 : 1) void chain_bwd_kernel(cons
         tile_gemm_lean<L>(nxt, a.layers[l].w, cur, lane);
         tile_act_w<L>(nxt, a.act, stage, lane);
         cur = nxt;
+        if constexpr (EXT) {
+          if (dnorm) {
+            tile_store_w<L>(stage, cur, a.AP[l], p0, nvalid, lane);
+            tile_layernorm<L>(cur, a.pn_gamma[l], a.pn_beta[l], a.eps, h);
+          }
+        }
       }
     }
     // ---- gradient arriving at the module's output ----
     Tile<L> dr;
     if (a.mode == AMBER_BWD_EDGE) {
       tile_load_row<L>(dr, a.dio, p, h);
-      const float inv = 1.0f / static_cast<float>(max(a.rowptr[d + 1] - a.rowptr[d], 1));  // scatter_mean's divisor
-      const f32x4* pm = reinterpret_cast<const f32x4*>(a.dm_in + static_cast<int64_t>(d) * L) + h;
+      if (!ln_outer) {
+        const float inv = 1.0f / static_cast<float>(max(a.rowptr[d + 1] - a.rowptr[d], 1));  // scatter_mean's divisor
+        const f32x4* pm = reinterpret_cast<const f32x4*>(a.dm_in + static_cast<int64_t>(d) * L) + h;
 #pragma unroll
-      for (int j = 0; j < L / 8; ++j) tile_set_chunk<L>(dr, j, tile_get_chunk<L>(dr, j) + inv * pm[2 * j]);
+        for (int j = 0; j < L / 8; ++j) tile_set_chunk<L>(dr, j, tile_get_chunk<L>(dr, j) + inv * pm[2 * j]);
+      }
     } else if (a.mode == AMBER_BWD_NODE) {
       tile_load_row<L>(dr, a.dio, p, h);
     } else {
@@ -250,9 +285,9 @@ __global__ __launch_bounds__(kBlock, L <= 64 ? 2 : 1) void chain_bwd_kernel(cons
     }
     if (!rowok) tile_zero<L>(dr);
     // ---- LayerNorm backward (statistics recomputed) ----
-    if (a.layer_norm == AMBER_MODE_INNER) {
+    if (a.layer_norm == AMBER_MODE_INNER || ln_outer) {
       Tile<L> xh = cur;
-      if (a.residual == AMBER_MODE_INNER) tile_add_row<L>(xh, a.rin, p, h);
+      if (res_in_ln) tile_add_row<L>(xh, a.rin, p, h);
       const float rstd = tile_ln_xhat<L>(xh, a.eps);
       tile_colsum_acc<L, FPL>(stage, dr, ps1, active, fo, lane);  // d beta
       // g = gamma * dy (in place), row means of g and g * xhat
@@ -279,14 +314,68 @@ __global__ __launch_bounds__(kBlock, L <= 64 ? 2 : 1) void chain_bwd_kernel(cons
 #pragma unroll
       for (int fb = 0; fb < L / 32; ++fb) dr.a[fb] = (dr.a[fb] - m1 - xh.a[fb] * m2) * rstd;
     }
+    // what joins the input gradient at the end besides W_in^T dh0: the residual term.  Inner residual: the gradient as it
+    // stands here, parked in dio.  Outer residual: the gradient that arrived at the block's output (after the outer
+    // LayerNorm's backward, if there is one) - dio still holds it unless the LayerNorm changed it.
+    const bool res_any = a.residual != AMBER_MODE_NONE;
+    if constexpr (EXT) {
+      if (ln_outer && a.mode == AMBER_BWD_EDGE) {
+        if (a.residual == AMBER_MODE_OUTER) tile_store_w<L>(stage, dr, a.dio, p0, nvalid, lane);
+        // the aggregate's gradient joins at e_mid, below the outer LayerNorm
+        const float inv = rowok ? 1.0f / static_cast<float>(max(a.rowptr[d + 1] - a.rowptr[d], 1)) : 0.f;
+        const f32x4* pm = reinterpret_cast<const f32x4*>(a.dm_in + static_cast<int64_t>(d) * L) + h;
+#pragma unroll
+        for (int j = 0; j < L / 8; ++j) tile_set_chunk<L>(dr, j, tile_get_chunk<L>(dr, j) + inv * pm[2 * j]);
+      }
+    }
     // ---- chain rule through the layers, last to first ----
     if (a.nl > 0) {
       const bool keep = a.residual == AMBER_MODE_INNER;
       if (keep) tile_store_w<L>(stage, dr, a.dio, p0, nvalid, lane);  // parked in memory until it joins the input gradient
-      if (a.nl > 1 || keep) wave_global_handover();  // rows stored above are re-read by other lanes of this wave
+      if (a.nl > 1 || res_any || dnorm) wave_global_handover();  // rows stored above are re-read by other lanes of this wave
+      // decoder LayerNorm behind layer l: dr arrives at n_l = LN_l(a_l) and leaves at a_l
+      auto post_norm_bwd = [&](int l) {
+        if constexpr (EXT) {
+          tile_load_row<L>(cur, a.AP[l], p, h);
+          const float rstd = tile_ln_xhat<L>(cur, a.eps);
+          const int64_t gw_l = (gw * a.nl + l) * 2 * L;
+          float pg[FPL], pb[FPL];
+#pragma unroll
+          for (int q = 0; q < FPL; ++q) pg[q] = pb[q] = 0.f;
+          tile_colsum_acc<L, FPL>(stage, dr, pb, active, fo, lane);  // d beta_l
+          wave_sync();
+          {
+            f32x4* sp = reinterpret_cast<f32x4*>(stage + c * stage_stride<L>()) + h;
+#pragma unroll
+            for (int j = 0; j < L / 8; ++j) sp[2 * j] = tile_get_chunk<L>(dr, j) * tile_get_chunk<L>(cur, j);
+          }
+          wave_sync();
+          if (active) {
+            for (int r = 0; r < kTile; ++r)
+#pragma unroll
+              for (int q = 0; q < FPL; ++q) pg[q] += stage[r * stage_stride<L>() + fo + q];
+#pragma unroll
+            for (int q = 0; q < FPL; ++q) {
+              a.pn_part[gw_l + fo + q] += pg[q];
+              a.pn_part[gw_l + L + fo + q] += pb[q];
+            }
+          }
+          const f32x4* gp = reinterpret_cast<const f32x4*>(a.pn_gamma[l]) + h;
+#pragma unroll
+          for (int j = 0; j < L / 8; ++j) tile_set_chunk<L>(dr, j, tile_get_chunk<L>(dr, j) * gp[2 * j]);
+          const float m1 = tile_row_sum<L>(dr) * (1.0f / L);
+          const float m2 = tile_row_dot<L>(dr, cur) * (1.0f / L);
+#pragma unroll
+          for (int fb = 0; fb < L / 32; ++fb) dr.a[fb] = (dr.a[fb] - m1 - cur.a[fb] * m2) * rstd;
+          tile_load_row<L>(cur, a.AP[l], p, h);  // a_l again, for act'
+        }
+      };
 #pragma unroll 1
       for (int l = a.nl - 1; l >= 1; --l) {
-        if (l != a.nl - 1) tile_load_row<L>(cur, a.A[l], p, h);
+        if (dnorm)
+          post_norm_bwd(l);
+        else if (l != a.nl - 1)
+          tile_load_row<L>(cur, a.A[l], p, h);
         tile_mul_dact<L>(dr, cur, a.act);
         tile_store_w<L>(stage, dr, a.DH[l], p0, nvalid, lane);
         Tile<L> nd;
@@ -294,16 +383,19 @@ __global__ __launch_bounds__(kBlock, L <= 64 ? 2 : 1) void chain_bwd_kernel(cons
         tile_gemm_lean<L>(nd, a.wT[l], dr, lane);
         dr = nd;
       }
-      if (a.nl > 1) tile_load_row<L>(cur, a.A[0], p, h);
+      if (dnorm)
+        post_norm_bwd(0);
+      else if (a.nl > 1)
+        tile_load_row<L>(cur, a.A[0], p, h);
       tile_mul_dact<L>(dr, cur, a.act);
       tile_store_w<L>(stage, dr, a.DH[0], p0, nvalid, lane);
-      if (a.mode == AMBER_BWD_NODE) {
+      if (has_m) {
         tile_zero<L>(cur);
         tile_gemm_lean<L>(cur, a.wT_m, dr, lane);
         tile_store_w<L>(stage, cur, a.dm_out, p0, nvalid, lane);
       }
       // gradient at the first layer's streamed input (+ the parked residual term; head: + what arrived at the latents)
-      if (keep || a.mode == AMBER_BWD_HEAD)
+      if (res_any || a.mode == AMBER_BWD_HEAD)
         tile_load_row<L>(cur, a.dio, p, h);
       else
         tile_zero<L>(cur);
@@ -337,14 +429,14 @@ __global__ __launch_bounds__(kBlock, L <= 64 ? 2 : 1) void chain_bwd_kernel(cons
 
 // out0[f] += sum_g part[g][0][f] (f < n0), out1[f] += sum_g part[g][1][f] (f < n1): one wave per output, lane j adds
 // the partials g = j, j + 64, ... in order and the lanes are combined by a fixed butterfly (deterministic)
-__global__ __launch_bounds__(64) void colpart_reduce_kernel(const float* __restrict__ part, int G, int L, float* __restrict__ out0, int n0,
-                                                            float* __restrict__ out1, int n1) {
+__global__ __launch_bounds__(64) void colpart_reduce_kernel(const float* __restrict__ part, int G, int64_t gstride, int L,
+                                                            float* __restrict__ out0, int n0, float* __restrict__ out1, int n1) {
   const int i = blockIdx.x;  // output (k, f)
   const int k = i / L, f = i % L;
   float* out = k == 0 ? out0 : out1;
   if (!out || f >= (k == 0 ? n0 : n1)) return;
   float s = 0.f;
-  for (int g = threadIdx.x; g < G; g += 64) s += part[(static_cast<int64_t>(g) * 2 + k) * L + f];
+  for (int g = threadIdx.x; g < G; g += 64) s += part[static_cast<int64_t>(g) * gstride + k * L + f];
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
   if (threadIdx.x == 0) out[f] += s;
@@ -694,7 +786,12 @@ int chain_bwd_grid(int64_t rows) {
 template <int L>
 static hipError_t launch_chain_bwd_t(const ChainBwdArgs& a, hipStream_t s) {
   const int64_t ntiles = cdiv(a.rows, kTile);
-  hipLaunchKernelGGL(chain_bwd_kernel<L>, dim3(chain_bwd_grid(a.rows)), dim3(kBlock), 0, s, a, ntiles);
+  const bool ext = a.residual == AMBER_MODE_OUTER || a.layer_norm == AMBER_MODE_OUTER ||
+                   (a.mode == AMBER_BWD_NODE && a.m == nullptr) || (a.mode == AMBER_BWD_HEAD && a.pn_gamma[0] != nullptr);
+  if (ext)
+    hipLaunchKernelGGL((chain_bwd_kernel<L, true>), dim3(chain_bwd_grid(a.rows)), dim3(kBlock), 0, s, a, ntiles);
+  else
+    hipLaunchKernelGGL((chain_bwd_kernel<L, false>), dim3(chain_bwd_grid(a.rows)), dim3(kBlock), 0, s, a, ntiles);
   return hipGetLastError();
 }
 hipError_t launch_chain_bwd(int L, const ChainBwdArgs& a, hipStream_t s) {
@@ -707,7 +804,62 @@ hipError_t launch_chain_bwd(int L, const ChainBwdArgs& a, hipStream_t s) {
   }
 }
 hipError_t launch_colpart_reduce(const float* part, int G, int L, float* out0, int n0, float* out1, int n1, hipStream_t s) {
-  hipLaunchKernelGGL(colpart_reduce_kernel, dim3(2 * L), dim3(64), 0, s, part, G, L, out0, n0, out1, n1);
+  hipLaunchKernelGGL(colpart_reduce_kernel, dim3(2 * L), dim3(64), 0, s, part, G, static_cast<int64_t>(2 * L), L, out0, n0, out1, n1);
+  return hipGetLastError();
+}
+hipError_t launch_colpart_reduce_strided(const float* part, int G, int64_t gstride, int L, float* out0, float* out1, hipStream_t s) {
+  hipLaunchKernelGGL(colpart_reduce_kernel, dim3(2 * L), dim3(64), 0, s, part, G, gstride, L, out0, L, out1, L);
+  return hipGetLastError();
+}
+
+__global__ void mul_dact_kernel(float* __restrict__ d, const float* __restrict__ a, int64_t n, int act) {
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const float av = a[i], dv = d[i];
+    if (act == AMBER_ACT_TANH)
+      d[i] = dv * (1.f - av * av);
+    else
+      d[i] = av > 0.f ? dv : (act == AMBER_ACT_LEAKYRELU ? 0.01f : 0.f) * dv;
+  }
+}
+hipError_t launch_mul_dact(float* d, const float* a, int64_t n, int act, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  int64_t grid = cdiv(n, 256);
+  if (grid > 256 * 32) grid = 256 * 32;
+  hipLaunchKernelGGL(mul_dact_kernel, dim3(static_cast<unsigned>(grid)), dim3(256), 0, s, d, a, n, act);
+  return hipGetLastError();
+}
+
+// the mean aggregate exactly as node_kernel forms it from the edge kernel's partial sums (same operations, same order)
+__global__ void partials_mean_kernel(const float* __restrict__ agg, const float* __restrict__ head, const float* __restrict__ tail,
+                                     const int32_t* __restrict__ rowptr, int red_shift, int64_t N, int L, float* __restrict__ out) {
+  const int lpr = L / 4;
+  const int64_t total = N * lpr;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total;
+       i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const int64_t n = i / lpr;
+    const int q = static_cast<int>(i % lpr);
+    const int r0 = rowptr[n], r1 = rowptr[n + 1];
+    f32x4 g = {0.f, 0.f, 0.f, 0.f};
+    if (r1 > r0) {
+      const int t0 = r0 >> red_shift, t1 = (r1 - 1) >> red_shift;
+      if (t0 == t1) {
+        g = reinterpret_cast<const f32x4*>(agg + n * L)[q];
+      } else {
+        g = reinterpret_cast<const f32x4*>(tail + static_cast<int64_t>(t0) * L)[q];
+        for (int t = t0 + 1; t <= t1; ++t) g += reinterpret_cast<const f32x4*>(head + static_cast<int64_t>(t) * L)[q];
+      }
+      g = g / static_cast<float>(r1 - r0);
+    }
+    reinterpret_cast<f32x4*>(out + n * L)[q] = g;
+  }
+}
+hipError_t launch_partials_mean(const float* agg, const float* head, const float* tail, const int32_t* rowptr, int red_shift,
+                                int64_t N, int L, float* out, hipStream_t s) {
+  if (N == 0) return hipSuccess;
+  int64_t grid = cdiv(N * (L / 4), 256);
+  if (grid > 256 * 32) grid = 256 * 32;
+  hipLaunchKernelGGL(partials_mean_kernel, dim3(static_cast<unsigned>(grid)), dim3(256), 0, s, agg, head, tail, rowptr, red_shift, N, L,
+                     out);
   return hipGetLastError();
 }
 

@@ -162,6 +162,7 @@ hipError_t launch_permute_rows(const float* in, const int32_t* perm, int64_t row
 // ---- backward (training), mpn_bwd.hip ----
 enum { AMBER_BWD_EDGE = 0, AMBER_BWD_NODE = 1, AMBER_BWD_HEAD = 2 };
 constexpr int kBwdMaxBlocks = 512;     // persistent grid of the chain kernel (4 waves a block, one partial per block)
+constexpr int kBwdWavesPerBlock = 4;   // = kWavesPerBlock of mpn_tile.h (checked in mpn_bwd.hip)
 constexpr int kWgradMaxChunks = 512;   // split-K chunks of a weight-gradient product
 // Recompute + chain rule of one module on 32-row tiles (see chain_bwd_kernel).  All matrices in the exact fp32 operand
 // order (launch_pack / launch_pack_t).
@@ -184,10 +185,15 @@ struct ChainBwdArgs {
   const float* wT[kMaxLayers];
   int32_t nl;             // layers of the chain (head: may be 0)
   int32_t act;
-  int32_t residual;       // AMBER_MODE_NONE / INNER
-  int32_t layer_norm;     // AMBER_MODE_NONE / INNER
+  int32_t residual;       // AMBER_MODE_*; node rows: OUTER only together with layer_norm INNER (the host folds the rest)
+  int32_t layer_norm;     // AMBER_MODE_*; node rows: NONE / INNER
   const float* gamma;
   float eps;
+  // head with a LayerNorm behind every decoder layer (latent_normalization "layer"), else pn_gamma[0] == nullptr
+  const float* pn_gamma[kMaxLayers];
+  const float* pn_beta[kMaxLayers];
+  float* AP[kMaxLayers];  // [rows,L] activation of layer l before its LayerNorm
+  float* pn_part;         // [grid waves][nl][2][L] (d gamma_l, d beta_l) sums, zeroed by the caller
   float* dio;             // [rows,L] in: gradient at the module's output; out: gradient at rin (head: added to)
   const float* dm_in;     // edge: [N,L] gradient at the mean aggregate (divided by the in-degree here)
   const float* dout;      // head: [N_m] gradient at the readout
@@ -201,6 +207,13 @@ struct ChainBwdArgs {
 int chain_bwd_grid(int64_t rows);
 hipError_t launch_chain_bwd(int L, const ChainBwdArgs& a, hipStream_t s);
 hipError_t launch_colpart_reduce(const float* part, int G, int L, float* out0, int n0, float* out1, int n1, hipStream_t s);
+// the same over partials that lie gstride floats apart (per-layer slots of pn_part)
+hipError_t launch_colpart_reduce_strided(const float* part, int G, int64_t gstride, int L, float* out0, float* out1, hipStream_t s);
+// d[i] *= act'(.) expressed through the activation's output a[i] (first layer of an embedding MLP)
+hipError_t launch_mul_dact(float* d, const float* a, int64_t n, int act, hipStream_t s);
+// out[n] = mean of the incoming edge rows from the edge kernel's partial sums (agg / head / tail), as the node kernel forms it
+hipError_t launch_partials_mean(const float* agg, const float* head, const float* tail, const int32_t* rowptr, int red_shift,
+                                int64_t N, int L, float* out, hipStream_t s);
 // weight-gradient products over the same rows, one launch (the matrices of one module)
 constexpr int kWgradMaxJobs = 6;
 struct WgradJob {

@@ -215,7 +215,8 @@ int amber_mpn_forward_timed(const AmberMpnDesc* desc, const float* params, const
  * loss.backward() on the output of SupervisedMPN.forward).
  *
  * amber_mpn_forward_train = amber_mpn_forward that additionally keeps the block inputs of every step on a
- * caller-owned TAPE (x_t[N,L], e_t[E,L] in CSR order, t = 0 .. num_steps * num_step_repeats;
+ * caller-owned TAPE (x_t[N,L], e_t[E,L] in CSR order, t = 0 .. num_steps * num_step_repeats; with an "outer" residual
+ * or LayerNorm also the mean aggregate m_t[N,L] of every step, which then is not a function of e_{t+1};
  * amber_mpn_tape_bytes).  amber_mpn_backward recomputes each module from its tape entry (activation checkpointing
  * per block) and writes the gradient of every parameter, in the layout of `params`, to grad_params
  * (amber_mpn_param_floats floats, overwritten).  Gradients arrive as any of
@@ -224,8 +225,10 @@ int amber_mpn_forward_timed(const AmberMpnDesc* desc, const float* params, const
  * rowptr_src / perm_src: the SOURCE-sorted order of the CSR positions, i.e. amber_mpn_csr_build applied to the
  * edge list [dst_sorted ; src_sorted] (its rowptr and perm outputs) -- used for the deterministic per-source sums.
  * Edge dropout (src/mpn/common/edge_dropout.py:24-25) happens before the call: the caller passes the kept edges.
- * Built for: residual / layer_norm none or inner, linear or constant embeddings, decoder activations relu /
- * leakyrelu / tanh without latent normalisation; everything else returns AMBER_ERR_UNSUPPORTED.
+ * Built for: latent 32 / 64 / 128; residual / layer_norm none, inner or outer (message_passing_block.py:62-74,91-97);
+ * constant, linear or LatentMLP embeddings (embedding.py:32-38); decoder activations relu / leakyrelu / tanh with
+ * latent_normalization none or layer (mlp.py:86-93).  Decoder BatchNorm, the other decoder activations and latent 256
+ * return AMBER_ERR_UNSUPPORTED.
  * ------------------------------------------------------------------------------------------------- */
 size_t amber_mpn_tape_bytes(const AmberMpnDesc* desc, int64_t num_nodes, int64_t num_edges);
 int amber_mpn_forward_train(const AmberMpnDesc* desc, const float* params, const float* packed, int64_t num_nodes,

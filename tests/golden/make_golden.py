@@ -101,12 +101,18 @@ CASES = {
     "decnorm_L32": (dict(latent=32, steps=1, dec_norm="layer", dec_act="silu"), "random", 4, 2, 23),
     "specnorm_L32": (dict(latent=32, steps=1, dec_spectral=True), "hier", 4, 2, 24),  # decoder spectral_norm (mlp.py:62-63)
     "L256_s2": (dict(latent=256, steps=2), "hier", 4, 2, 25),  # the upper end of north_star's latent range (64-256)
+    # training breadth: decoder LayerNorm with an activation the backward takes; 3-layer MLP embeddings; outer modes with
+    # step repeats on a hub graph
+    "decnorm_lrelu_L32": (dict(latent=32, steps=1, dec_norm="layer", dec_layers=3), "random", 4, 2, 26),
+    "embmlp3_tanh_L64": (dict(latent=64, steps=1, act="tanh", dec_act="tanh", embedding={"mlp": mlp_cfg("tanh", 3)}), "hier", 4, 2, 27),
+    "outer_hier_L64": (dict(latent=64, steps=2, repeats=2, residual="outer", layer_norm="outer"), "hier", 4, 2, 28),
 }
 
 
 # cases inside what amber_mpn_backward is built for (include/amber_mpn.h)
 TRAINABLE = ("debug_L64_s2", "synth_L128_s2", "hier_L64_s3", "none_tanh_L32", "const_edge_L32", "const_node_L32", "repeat_L32_l3",
-             "specnorm_L32")
+             "specnorm_L32", "outer_relu_L32", "mix_io_L32", "mix_oi_L32", "embmlp_L32", "decnorm_lrelu_L32", "embmlp3_tanh_L64",
+             "outer_hier_L64")
 
 
 def main():
@@ -154,7 +160,8 @@ def main():
             (out_g * grad_out).sum().backward()  # REFERENCE backward
             blob["grad_out"] = grad_out.numpy()
             for pname, p in model.named_parameters():
-                blob[f"grad/{pname}"] = p.grad.detach().numpy()
+                # None: the output does not depend on the parameter (outer LayerNorm of the LAST block's edges) = zero
+                blob[f"grad/{pname}"] = (p.grad if p.grad is not None else torch.zeros_like(p)).detach().numpy()
         path = os.path.join(HERE, f"{name}.npz")
         np.savez_compressed(path, **blob)
         print(f"{name}: N={g.x.shape[0]} E={g.edge_index.shape[1]} params={sum(p.numel() for p in model.parameters())} "

@@ -24,7 +24,8 @@ def _oracle_grads(cfg, params, x, edge_attr, edge_index, mask, grad_out):
     p = {k: v.clone().requires_grad_(not k.endswith(("weight_u", "weight_v"))) for k, v in params.items()}
     out = orc.supervised_mpn_forward(p, cfg, x, edge_attr, edge_index, mask)
     (out * grad_out).sum().backward()
-    return {k: v.grad for k, v in p.items() if v.requires_grad}
+    # no dependency (the outer LayerNorm of the last block's edges): autograd leaves None, the gradient is zero
+    return {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in p.items() if v.requires_grad}
 
 
 @pytest.mark.parametrize("name", TRAINABLE)
@@ -78,11 +79,17 @@ def test_training_size_queries_and_validation():
     assert lib.amber_mpn_tape_bytes(C.byref(d), n, e) == a256(t1 * n * 64 * 4) + a256(t1 * e * 64 * 4) + 256
     assert lib.amber_mpn_backward_workspace_bytes(C.byref(d), n, e) >= lib.amber_mpn_workspace_bytes(C.byref(d), n, e)
     # configurations the backward kernels do not take are refused by name, before any pointer is touched
-    for bad, word in ((dict(residual="outer"), b"outer"), (dict(embed_layers=2), b"embeddings"),
-                      (dict(decoder_activation="gelu"), b"decoder activation"), (dict(decoder_norm="layer"), b"latent_normalization")):
+    for bad, word in ((dict(decoder_activation="gelu"), b"decoder activation"), (dict(decoder_norm="batch"), b"BatchNorm"),
+                      (dict(latent=256), b"latent_dimension 256")):
         db = engine.make_desc(**{**kw, **bad})
         rc = lib.amber_mpn_forward_train(C.byref(db), 0, 0, n, e, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0)
         assert rc == -2 and word in lib.amber_mpn_last_error()
+    # an "outer" residual / LayerNorm also keeps the mean aggregate of every step application on the tape
+    do = engine.make_desc(**{**kw, "residual": "outer"})
+    assert lib.amber_mpn_tape_bytes(C.byref(do), n, e) == a256(t1 * n * 64 * 4) + a256(t1 * e * 64 * 4) + a256((t1 - 1) * n * 64 * 4) + 256
+    # MLP embeddings and the decoder's LayerNorm need row buffers of their own
+    dm = engine.make_desc(**{**kw, "embed_layers": 4, "decoder_norm": "layer"})
+    assert lib.amber_mpn_backward_workspace_bytes(C.byref(dm), n, e) > lib.amber_mpn_backward_workspace_bytes(C.byref(d), n, e)
     rc = lib.amber_mpn_backward(C.byref(d), 0, 0, n, e, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0)
     assert rc == -1 and b"NULL" in lib.amber_mpn_last_error()
 
