@@ -70,6 +70,9 @@ def parse():
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="development only: run the N > 1 code path with every rank on cuda:0 and the gloo backend (a one-GPU "
                          "box cannot host RCCL ranks); the printed value is NOT a scaling measurement")
+    ap.add_argument("--init-dist", action="store_true",
+                    help="initialise the process group (RCCL) even with one rank: exercises on a one-GPU box the RCCL start-up, "
+                         "barriers and gathers that the N > 1 runs use (launch under torch.distributed.run --nproc-per-node 1)")
     ap.add_argument("--cpu-graphs", type=int, default=10, help="graphs in the CPU-baseline sample (10 = 1M edges)")
     args = ap.parse_args()
     if args.scaling is None:
@@ -155,7 +158,7 @@ def init_ranks(args):
     dev = torch.device("cuda", 0 if args.rehearse_on_one_gpu else local_rank)
     torch.cuda.set_device(dev)
     dist = None
-    if world > 1:
+    if world > 1 or args.init_dist:
         import torch.distributed as dist
 
         if args.rehearse_on_one_gpu:
