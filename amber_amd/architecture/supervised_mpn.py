@@ -149,4 +149,5 @@ class SupervisedMPN(nn.Module):
                 _lib.ptr(nm), _lib.ptr(nv), _lib.ptr(em), _lib.ptr(ev), _lib.ptr(pm), _lib.ptr(pv), _lib.ptr(baseline), out.data_ptr(),
                 ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev))
         _lib.check(rc, "predict")
+        csr.check()
         return out

@@ -6,6 +6,7 @@ destination's row the edges keep the reference's edge order.
 """
 from __future__ import annotations
 
+import os
 import weakref
 from dataclasses import dataclass
 from typing import Optional
@@ -23,6 +24,48 @@ class CSR:
     src_sorted: torch.Tensor  # int32 [E]
     dst_sorted: torch.Tensor  # int32 [E]
     perm: torch.Tensor        # int32 [E]: original edge id at sorted position p
+
+    def check(self, wait: bool = False) -> None:
+        """Deferred index validation (build_csr(validate="deferred")): raises IndexError once the status word of the build
+        has reached the host and says that edge_index held node ids outside [0, N).  wait=False only looks (no
+        synchronisation); wait=True blocks until the word is there."""
+        pending = getattr(self, "_pending", None)
+        if pending is None:
+            return
+        host, event = pending
+        if wait:
+            event.synchronize()
+        elif not event.query():
+            return
+        self._pending = None
+        if int(host[0]) != 0:
+            raise IndexError(f"edge_index contains node ids outside [0, {self.num_nodes})")
+
+
+class _StatusRing:
+    """Pinned host words for the deferred status read-backs (allocating pinned memory per mesh would cost more than the
+    synchronisation it avoids).  A slot is handed out again only after its previous owner has been checked."""
+
+    def __init__(self, slots: int = 64):
+        self.slots = slots
+        self.host = None
+        self.owner = [None] * slots
+        self.next = 0
+
+    def take(self, csr: "CSR") -> torch.Tensor:
+        if self.host is None:
+            self.host = torch.zeros(self.slots, dtype=torch.int32).pin_memory()
+        i = self.next
+        self.next = (i + 1) % self.slots
+        old = self.owner[i]() if self.owner[i] is not None else None
+        if old is not None:
+            old.check(wait=True)  # an unchecked build of 64 meshes ago: its verdict must not be lost
+        self.owner[i] = weakref.ref(csr)
+        return self.host[i:i + 1]
+
+
+_status_ring = _StatusRing()
+_STRICT = bool(os.environ.get("AMBER_CSR_STRICT"))  # diagnostic: validate every build at once (a synchronisation per mesh)
 
 
 def source_order(csr: CSR):
@@ -50,14 +93,22 @@ def _require_cuda(t: torch.Tensor, name: str) -> None:
         )
 
 
-def build_csr(edge_index: torch.Tensor, num_nodes: int, validate: bool = True) -> CSR:
+def build_csr(edge_index: torch.Tensor, num_nodes: int, validate=True) -> CSR:
     """Build the CSR for edge_index[2, E] (row 0 = source, row 1 = destination).
 
     `validate=True` reads back one status word (a device synchronisation, once per mesh) and raises
     IndexError when an index lies outside [0, num_nodes), the error torch indexing would raise.
+    `validate="deferred"` (the model's own path: AMBER's refinement loop brings a new mesh every iteration) copies the
+    word to pinned host memory behind the build WITHOUT waiting; `CSR.check()` - called by every forward before and after
+    it queues its kernels - raises the same IndexError as soon as the word has arrived, at the latest on the next use of
+    the CSR or after 64 further builds.  That is also when torch's own GPU indexing would report it (a device-side assert
+    surfaces at the next synchronisation).  The CSR of an invalid edge_index is memory-safe either way: the builder clamps
+    the ids it stores.
     """
     lib = _lib.load()
     _require_cuda(edge_index, "edge_index")
+    if validate == "deferred" and _STRICT:
+        validate = True
     if edge_index.dim() != 2 or edge_index.shape[0] != 2:
         raise ValueError(f"Edge index must have shape (2, num_edges), given '{tuple(edge_index.shape)}' instead.")
     ei = edge_index.long().contiguous()
@@ -74,9 +125,16 @@ def build_csr(edge_index: torch.Tensor, num_nodes: int, validate: bool = True) -
         rc = lib.amber_mpn_csr_build(ei.data_ptr(), E, N, rowptr.data_ptr(), src_sorted.data_ptr(), dst_sorted.data_ptr(),
                                      perm.data_ptr(), status.data_ptr(), ws.data_ptr(), ws_bytes, _lib.stream_ptr(dev))
     _lib.check(rc, "csr_build")
-    if validate and int(status.item()) != 0:
+    csr = CSR(N, E, rowptr, src_sorted, dst_sorted, perm)
+    if validate == "deferred":
+        host = _status_ring.take(csr)
+        host.copy_(status, non_blocking=True)
+        event = torch.cuda.Event()
+        event.record(torch.cuda.current_stream(dev))
+        csr._pending = (host, event)
+    elif validate and int(status.item()) != 0:
         raise IndexError(f"edge_index contains node ids outside [0, {N})")
-    return CSR(N, E, rowptr, src_sorted, dst_sorted, perm)
+    return csr
 
 
 class CSRCache:
@@ -91,8 +149,9 @@ class CSRCache:
     def get(self, edge_index: torch.Tensor, num_nodes: int) -> CSR:
         for ref, version, n, csr in self._entries:
             if ref() is edge_index and version == edge_index._version and n == num_nodes:
+                csr.check()
                 return csr
-        csr = build_csr(edge_index, num_nodes)
+        csr = build_csr(edge_index, num_nodes, validate="deferred")
         self._entries = [e for e in self._entries if e[0]() is not None][-(self.capacity - 1):] if self.capacity > 1 else []
         self._entries.append((weakref.ref(edge_index), edge_index._version, num_nodes, csr))
         return csr
@@ -105,7 +164,7 @@ def csr_of(graph, num_nodes: int, cache: Optional[CSRCache]) -> CSR:
         return pre
     if cache is not None:
         return cache.get(graph.edge_index, num_nodes)
-    return build_csr(graph.edge_index, num_nodes)
+    return build_csr(graph.edge_index, num_nodes, validate="deferred")
 
 
 def segment_mean(values_sorted: torch.Tensor, rowptr: torch.Tensor) -> torch.Tensor:

@@ -128,9 +128,11 @@ def forward(desc: _lib.AmberMpnDesc, flat: torch.Tensor, packed: torch.Tensor, x
             cnt = (C.c_int32 * _lib.NUM_KERNEL_CLASSES)()
             rc = lib.amber_mpn_forward_timed(*args, ms, cnt)
             _lib.check(rc, "forward")
+            csr.check()
             return out_node, out_edge, out_sizing, list(ms), list(cnt)
         rc = lib.amber_mpn_forward(*args)
     _lib.check(rc, "forward")
+    csr.check()  # deferred index validation of a freshly built CSR: its status word has usually arrived by now
     return out_node, out_edge, out_sizing
 
 
@@ -254,6 +256,7 @@ class MpnFunction(torch.autograd.Function):
                 _lib.ptr(out_edge), _lib.ptr(out_sizing), tape.data_ptr(), tape.numel(), ws.data_ptr(), ws.numel(),
                 _lib.stream_ptr(dev))
         _lib.check(rc, "forward_train")
+        csr.check()
         ctx.desc, ctx.csr, ctx.out_index = desc, csr, out_index
         ctx.x, ctx.edge_attr, ctx.flat, ctx.packed, ctx.tape = x, edge_attr, flat, packed, tape
         ctx.shapes = [tuple(p.shape) for p in params]

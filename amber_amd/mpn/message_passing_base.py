@@ -95,7 +95,7 @@ class MessagePassingBase(nn.Module):
         if self.training and self.maybe_edge_dropout is not noop and self.maybe_edge_dropout.dropout_prob > 0.0:
             work = graph if not self._create_graph_copy else _LatentGraph(graph, graph.x, graph.edge_attr)
             self.maybe_edge_dropout(work)
-            return work, build_csr(work.edge_index, int(work.x.shape[0]))
+            return work, build_csr(work.edge_index, int(work.x.shape[0]), validate="deferred")
         return graph, csr_of(graph, int(graph.x.shape[0]), self._csr_cache)
 
     def transform_to_features(self, graph):

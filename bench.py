@@ -278,6 +278,7 @@ def main():
     def resident(g):
         gd = g.to(dev)
         nn = int(gd.x.shape[0])
+        csr_mod.build_csr(gd.edge_index, nn)  # the process's first build carries one-off costs (code objects, allocator): not timed
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         gd.amber_csr = csr_mod.build_csr(gd.edge_index, nn)  # once per mesh, outside the timed region
@@ -393,6 +394,20 @@ def main():
         lat.sort()
         kernels["wall_ms_per_call_waited_median"] = lat[len(lat) // 2]
         kernels["wall_ms_per_call_pipelined"] = per_rank[0][2] / args.steps * 1e3
+        # what AMBER's refinement loop sees: every iteration brings a NEW mesh, so the destination sort is part of the call
+        # (a fresh edge_index tensor per call: the per-mesh CSR cache cannot hit); warmed, unlike csr_build_ms_once_per_mesh,
+        # which is the first CSR build of the process
+        fresh = []
+        for _ in range(max(5, min(20, args.steps))):
+            g2 = type(gd)(x=gd.x, edge_attr=gd.edge_attr, edge_index=gd.edge_index.clone(), batch=gd.batch, mask_output=gd.mask_output)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            with torch.no_grad():
+                model(g2)
+            torch.cuda.synchronize(dev)
+            fresh.append((time.perf_counter() - t0) * 1e3)
+        fresh.sort()
+        kernels["wall_ms_per_call_new_mesh_median"] = fresh[len(fresh) // 2]
         kernels["launches_per_forward"] = sum(cnt) // reps
         if world == 1 and not args.no_cpu_baseline and args.workload == "config5":
             cpu = cpu_baseline(cfg, state_dict, args)

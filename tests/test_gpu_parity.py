@@ -378,3 +378,29 @@ def test_large_batch_properties_other_widths(gpu_device, latent, steps, graphs):
         e0, e1 = int(g.edge_ptr[gi]), int(g.edge_ptr[gi + 1])
         want = orc.supervised_mpn_forward(sd, cfg, g.x[n0:n1], g.edge_attr[e0:e1], g.edge_index[:, e0:e1] - n0, None)
         assert close(out1[n0:n1].cpu(), want)
+
+
+def test_deferred_index_validation_surfaces_on_the_model_path(gpu_device):
+    """The model's own CSR builds do not synchronise (a new mesh every refinement iteration): the status word travels to
+    pinned host memory behind the build, and the IndexError is raised once it has arrived - at the latest by an explicit
+    check or the next use of that graph.  The CSR of the invalid edge list is memory-safe (clamped ids) meanwhile."""
+    cfg, params, d = load_golden("debug_L64_s2")
+    model = SupervisedMPN(AttrDict(cfg), syn.GraphBatch(x=d["x"], edge_attr=d["edge_attr"]))
+    model.load_state_dict(params, strict=True)
+    model = model.to(gpu_device).eval()
+    bad = d["edge_index"].clone()
+    bad[1, 5] = d["x"].shape[0] + 7
+    g = syn.GraphBatch(x=d["x"].to(gpu_device), edge_attr=d["edge_attr"].to(gpu_device), edge_index=bad.to(gpu_device),
+                       batch=d["batch"].to(gpu_device), mask_output=d["mask_output"].to(gpu_device))
+    with pytest.raises(IndexError):
+        with torch.no_grad():
+            model(g)  # usually raises here already (the word arrives while the forward's launches are queued) ...
+            torch.cuda.synchronize()
+            model(g)  # ... and certainly on the next use of the graph
+    # a deferred build can be checked explicitly
+    csr = csr_mod.build_csr(bad.to(gpu_device), int(d["x"].shape[0]), validate="deferred")
+    with pytest.raises(IndexError):
+        csr.check(wait=True)
+    ok = csr_mod.build_csr(d["edge_index"].to(gpu_device), int(d["x"].shape[0]), validate="deferred")
+    ok.check(wait=True)
+    assert getattr(ok, "_pending") is None
