@@ -51,6 +51,7 @@ struct Layout {
   std::vector<int64_t> eg, eb, ng, nb;  // LayerNorm params per step (or -1)
   MlpLayout dec;
   int64_t dec_f2[kMaxLayers];  // packed offsets of the decoder matrices in the split-precision format, or -1
+  int64_t node_fold;           // packed offset of the folded node tables [3][F_n + 1][L] (embed_proj_kernel), or -1
   int64_t readout_w, readout_b;
   int64_t n_params, n_packed;
 };
@@ -85,6 +86,7 @@ int validate(const AmberMpnDesc* d) {
 }
 
 bool use_fast_head(const AmberMpnDesc& d);
+bool use_node_fold(const AmberMpnDesc& d);
 
 Layout build_layout(const AmberMpnDesc& d) {
   Layout lay;
@@ -168,6 +170,11 @@ Layout build_layout(const AmberMpnDesc& d) {
     po += L;
     lay.readout_b = po;
     po += 1;
+  }
+  lay.node_fold = -1;
+  if (use_node_fold(d)) {
+    lay.node_fold = pk;
+    pk += (3 * (d.in_node_features + 1) * L + 63) / 64 * 64;
   }
   lay.n_params = po;
   lay.n_packed = pk;
@@ -301,6 +308,13 @@ bool use_fast_node(const AmberMpnDesc& d) {
 bool use_fast_head(const AmberMpnDesc& d) {
   return d.has_head && use_fast_node(d) && d.num_steps * d.num_step_repeats > 0 &&
          head_f2_supported(d.decoder_layers, d.decoder_activation, d.decoder_norm) && !env_switches().no_fused_head;
+}
+// The node embedding and the first step's projections run as ONE pass over the raw node features (embed_proj_kernel) when
+// the embedding is linear or constant; tables in the packed buffer.  (Switched off together with the fused edge embedding
+// by AMBER_MPN_NO_FUSED_EMBED.)
+bool use_node_fold(const AmberMpnDesc& d) {
+  return d.num_steps * d.num_step_repeats > 0 && (d.in_node_features == 0 || d.embed_layers == 0) &&
+         d.in_node_features <= kMaxFoldNodeFeatures && !env_switches().no_fused_embed;
 }
 int device_cus() {
   constexpr int kMaxDevices = 64;
@@ -465,8 +479,16 @@ int forward_impl(const AmberMpnDesc* desc, const float* params, const float* pac
   auto xbuf = [&](int t) { return tape ? tp.x + static_cast<size_t>(t) * N * L : w.x; };
   auto ebuf = [&](int t) { return tape ? tp.e + static_cast<size_t>(t) * E * L : w.e; };
 
-  rc = run_embedding(d, lay.node_embed, d.in_node_features, params, packed, x, N, nullptr, xbuf(0), s, tm);
-  if (rc) return rc;
+  const bool fold_node = lay.node_fold >= 0;  // x_0, P_s, P_d of step 0 in one pass over the raw features
+  if (fold_node) {
+    tm.begin(AMBER_KC_EMBED);
+    hipError_t e = launch_embed_proj(L, x, N, d.in_node_features, packed + lay.node_fold, xbuf(0), w.Ps, w.Pd, s);
+    tm.end();
+    HIP_TRY(e, "node embedding + projection kernel");
+  } else {
+    rc = run_embedding(d, lay.node_embed, d.in_node_features, params, packed, x, N, nullptr, xbuf(0), s, tm);
+    if (rc) return rc;
+  }
   // The linear (or constant) edge embedding of few raw features is fused into the first edge step: its rows are
   // computed there on the fly and e is first written by that step.
   const bool fuse_edge_embed = !tape && iters > 0 && use_fast_edge(d) && d.in_edge_features <= kMaxFusedEmbed &&
@@ -500,7 +522,7 @@ int forward_impl(const AmberMpnDesc* desc, const float* params, const float* pac
     }
     return AMBER_OK;
   }
-  {  // first-layer projections of step 0
+  if (!fold_node) {  // first-layer projections of step 0
     NodeArgs a{};
     a.N = N;
     a.x_in = xbuf(0);
@@ -1028,6 +1050,12 @@ int amber_mpn_pack_weights(const AmberMpnDesc* desc, const float* params, float*
         HIP_TRY(pack_one(FMT_F2, params + lay.dec.W[l], L, 0, 0, L, 1, packed + lay.dec_f2[l]), "pack decoder (split precision)");
   }
   HIP_TRY(flush(), "pack weights");
+  if (lay.node_fold >= 0) {
+    const int F = desc->in_node_features;
+    HIP_TRY(launch_fold_node_tables(L, F, F > 0 ? params + lay.node_embed.W[0] : nullptr, params + lay.node_embed.B[0],
+                                    params + lay.edge[0].W[0], params + lay.edge[0].B[0], packed + lay.node_fold, s),
+            "fold node tables");
+  }
   return AMBER_OK;
 }
 

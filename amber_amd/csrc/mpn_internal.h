@@ -130,6 +130,12 @@ hipError_t launch_node(int L, const NodeArgs& a, hipStream_t s);
 // out[r] = act(W in[idx(r)] + b): small-K linear (K = F >= 0), idx = perm gather or identity
 hipError_t launch_embed(int L, const float* in, int64_t rows, int F, const float* W, const float* b, const int32_t* perm,
                         int act_or_neg1, float* out, hipStream_t s);
+// x = A raw + b, P_s = W0s x, P_d = W0d x + b0 from the raw node features through tables [3][F + 1][L] (see embed_proj_kernel)
+constexpr int kMaxFoldNodeFeatures = 16;
+hipError_t launch_embed_proj(int L, const float* in, int64_t rows, int F, const float* tables, float* out_x, float* out_ps,
+                             float* out_pd, hipStream_t s);
+hipError_t launch_fold_node_tables(int L, int F, const float* A, const float* b, const float* W0, const float* b0, float* tables,
+                                   hipStream_t s);
 // re-tile W[L, ld] columns [col0, col0+L) into MFMA operand order
 hipError_t launch_pack(int L, const float* W, int ld, int col0, float* out, hipStream_t s);
 // A packed matrix is L*L floats of body + kPackedHeader floats (split-precision formats keep their scales there).

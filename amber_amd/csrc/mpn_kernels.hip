@@ -282,6 +282,62 @@ __global__ __launch_bounds__(256) void embed_kernel(const float* __restrict__ in
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// K0 and the first step's projections in one pass over the raw node features.  The node embedding is linear (or a
+// learned constant), so the projections of the embedded rows are linear in the raw features as well:
+//   x = A raw + b,   P_s = W0s x = (W0s A) raw + W0s b,   P_d = W0d x + b0 = (W0d A) raw + (W0d b + b0)
+// with tables [3][F + 1][L] (row F: the constant) formed once per weight update (fold_node_tables_kernel, called by
+// amber_mpn_pack_weights).  One write-bound kernel replaces the embedding kernel and a projection launch of the node
+// kernel (which re-read x for two contractions).  x is computed with the embedding kernel's own operations (bit-equal).
+// reference: Embedding.forward (src/mpn/common/embedding.py:44-54), first layer of MessagePassingEdgeModule's MLP on
+// [x_s, x_d, e] (src/mpn/message_passing_modules.py:46-52)
+// ---------------------------------------------------------------------------------------------------
+template <int L>
+__global__ __launch_bounds__(256) void embed_proj_kernel(const float* __restrict__ in, int64_t rows, int F,
+                                                         const float* __restrict__ tables, float* __restrict__ out_x,
+                                                         float* __restrict__ out_ps, float* __restrict__ out_pd) {
+  extern __shared__ __attribute__((aligned(16))) float tb[];  // [3][F + 1][L]
+  const int TL = (F + 1) * L;
+  for (int i = threadIdx.x; i < 3 * TL; i += blockDim.x) tb[i] = tables[i];
+  __syncthreads();
+  constexpr int LPR = L / 4;
+  constexpr int RPB = 256 / LPR;
+  const int q = threadIdx.x % LPR;
+  f32x4 c[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) c[t] = reinterpret_cast<const f32x4*>(tb + t * TL + F * L)[q];
+  for (int64_t r = static_cast<int64_t>(blockIdx.x) * RPB + threadIdx.x / LPR; r < rows;
+       r += static_cast<int64_t>(gridDim.x) * RPB) {
+    f32x4 acc[3] = {c[0], c[1], c[2]};
+    for (int k = 0; k < F; ++k) {
+      const float xv = in[r * F + k];
+#pragma unroll
+      for (int t = 0; t < 3; ++t) acc[t] += xv * reinterpret_cast<const f32x4*>(tb + t * TL + k * L)[q];
+    }
+    reinterpret_cast<f32x4*>(out_x + r * L)[q] = acc[0];
+    reinterpret_cast<f32x4*>(out_ps + r * L)[q] = acc[1];
+    reinterpret_cast<f32x4*>(out_pd + r * L)[q] = acc[2];
+  }
+}
+// tables[0][k][j] = A[j][k], [0][F][j] = b[j];  tables[1] = W0s (A | b);  tables[2] = W0d (A | b) (+ b0 in row F);
+// W0 = first layer of the step-0 edge MLP, [L, 3 L] row-major; A = node embedding weight [L, F] (nullptr: F = 0)
+__global__ void fold_node_tables_kernel(const float* __restrict__ A, const float* __restrict__ b, const float* __restrict__ W0,
+                                        const float* __restrict__ b0, int L, int F, float* __restrict__ tables) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // (t, k, j)
+  if (i >= 3 * (F + 1) * L) return;
+  const int j = i % L, k = (i / L) % (F + 1), t = i / (L * (F + 1));
+  float v;
+  if (t == 0) {
+    v = k < F ? A[j * F + k] : b[j];
+  } else {
+    const float* wr = W0 + static_cast<int64_t>(j) * (3 * L) + (t - 1) * L;
+    float sum = 0.f;
+    for (int m = 0; m < L; ++m) sum = fmaf(wr[m], k < F ? A[m * F + k] : b[m], sum);
+    v = (t == 2 && k == F) ? sum + b0[j] : sum;
+  }
+  tables[i] = v;
+}
+
 // Re-tile columns [col0, col0 + L) of W[L, ld] into MFMA operand order:
 // out[((j * L/32 + fb) * 64 + lane) * 4 + t] = W[32 fb + (lane & 31)][col0 + 8 j + 4 (lane >> 5) + t]
 template <int L>
@@ -361,6 +417,25 @@ static hipError_t launch_embed_t(const float* in, int64_t rows, int F, const flo
   return hipGetLastError();
 }
 template <int L>
+static hipError_t launch_embed_proj_t(const float* in, int64_t rows, int F, const float* tables, float* out_x, float* out_ps,
+                                      float* out_pd, hipStream_t s) {
+  if (rows == 0) return hipSuccess;
+  constexpr int RPB = 256 / (L / 4);
+  int64_t grid = cdiv(rows, RPB);
+  if (grid > 256 * 16) grid = 256 * 16;
+  const size_t lds = static_cast<size_t>(3) * (F + 1) * L * sizeof(float);
+  static thread_local size_t allowed = 0;  // dynamic LDS beyond 64 KB must be allowed per function
+  if (lds > 64 * 1024 && lds > allowed) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(embed_proj_kernel<L>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       static_cast<int>(lds));
+    if (e != hipSuccess) return e;
+    allowed = lds;
+  }
+  hipLaunchKernelGGL(embed_proj_kernel<L>, dim3(static_cast<unsigned>(grid)), dim3(256), lds, s, in, rows, F, tables, out_x, out_ps,
+                     out_pd);
+  return hipGetLastError();
+}
+template <int L>
 static hipError_t launch_pack_t(const float* W, int ld, int col0, float* out, hipStream_t s) {
   hipLaunchKernelGGL(pack_kernel<L>, dim3(cdiv(L * L / 4, 256)), dim3(256), 0, s, W, ld, col0, out);
   return hipGetLastError();
@@ -395,6 +470,22 @@ hipError_t launch_node(int L, const NodeArgs& a, hipStream_t s) {
     case 256: return launch_node_t<256>(a, s);
     default: return hipErrorInvalidValue;
   }
+}
+hipError_t launch_embed_proj(int L, const float* in, int64_t rows, int F, const float* tables, float* out_x, float* out_ps,
+                             float* out_pd, hipStream_t s) {
+  switch (L) {
+    case 32: return launch_embed_proj_t<32>(in, rows, F, tables, out_x, out_ps, out_pd, s);
+    case 64: return launch_embed_proj_t<64>(in, rows, F, tables, out_x, out_ps, out_pd, s);
+    case 128: return launch_embed_proj_t<128>(in, rows, F, tables, out_x, out_ps, out_pd, s);
+    case 256: return launch_embed_proj_t<256>(in, rows, F, tables, out_x, out_ps, out_pd, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+hipError_t launch_fold_node_tables(int L, int F, const float* A, const float* b, const float* W0, const float* b0, float* tables,
+                                   hipStream_t s) {
+  const int total = 3 * (F + 1) * L;
+  hipLaunchKernelGGL(fold_node_tables_kernel, dim3((total + 255) / 256), dim3(256), 0, s, A, b, W0, b0, L, F, tables);
+  return hipGetLastError();
 }
 hipError_t launch_embed(int L, const float* in, int64_t rows, int F, const float* W, const float* b, const int32_t* perm,
                         int act, float* out, hipStream_t s) {

@@ -50,10 +50,14 @@ def test_param_count_matches_survey_formula():
     # packed: per step 3 + 1 edge matrices, 2 + 1 node matrices; 2 decoder matrices in the exact format (stand-alone head,
     # training) and, in the split-precision modes, 2 more in the format of the node launch the head rides on; each L*L body
     # + 8-float header
+    # ... and the folded tables of the node embedding + first projections, [3][F_n + 1][L] floats rounded up to 64
     heads = 4 if engine.default_precision != "fp32" else 2
-    assert lib.amber_mpn_packed_floats(C.byref(d)) == (2 * 7 + heads) * (64 * 64 + 8)
+    fold = (3 * (5 + 1) * 64 + 63) // 64 * 64
+    assert lib.amber_mpn_packed_floats(C.byref(d)) == (2 * 7 + heads) * (64 * 64 + 8) + fold
     d32 = _desc(has_head=True, decoder_layers=2, precision="fp32")
-    assert lib.amber_mpn_packed_floats(C.byref(d32)) == (2 * 7 + 2) * (64 * 64 + 8)
+    assert lib.amber_mpn_packed_floats(C.byref(d32)) == (2 * 7 + 2) * (64 * 64 + 8) + fold
+    dmlp = _desc(has_head=True, decoder_layers=2, precision="fp32", embed_layers=2)  # MLP embedding: no fold
+    assert lib.amber_mpn_packed_floats(C.byref(dmlp)) == (2 * 7 + 2 + 2) * (64 * 64 + 8)
 
 
 def test_descriptor_validation_reports_errors():
