@@ -1039,8 +1039,9 @@ int amber_mpn_pack_weights(const AmberMpnDesc* desc, const float* params, float*
   HIP_TRY(pack_mlp(lay.edge_embed, 0), "pack edge embedding");
   for (int st = 0; st < desc->num_steps; ++st) {
     const int fe = use_fast_edge(*desc) ? FMT_F2 : FMT_F32, fn = use_fast_node(*desc) ? FMT_F2 : FMT_F32;
-    // W0s / W0d are applied by the node kernel to x' in accumulator registers, W0e by the edge kernel to rows of e
-    HIP_TRY(pack_mlp(lay.edge[st], 3, fn, fn, fe, false, fe, 0b011), "pack edge MLP");
+    // W0s / W0d are applied by the node kernel to x' in accumulator registers, W0e by the edge kernel to the rows of e,
+    // which it also holds in accumulator layout: the k order of all three follows the permuted columns
+    HIP_TRY(pack_mlp(lay.edge[st], 3, fn, fn, fe, false, fe, 0b111), "pack edge MLP");
     HIP_TRY(pack_mlp(lay.node[st], 2, fn, fn, FMT_F32, true, fn), "pack node MLP");
   }
   if (desc->has_head) {

@@ -53,6 +53,12 @@ constexpr int kStamps = 12;
 #define STAMP(k)
 #endif
 
+#ifndef AMBER_KSTEP_GROUP_NODE
+#define AMBER_KSTEP_GROUP_NODE 2
+#endif
+#ifndef AMBER_KSTEP_GROUP
+#define AMBER_KSTEP_GROUP 2
+#endif
 #ifndef AMBER_NODE_RELOAD_V
 #define AMBER_NODE_RELOAD_V 0
 #endif
@@ -270,23 +276,29 @@ struct ELanding {
 // one 16-deep k-step of all feature blocks: acc[fb] += A(hi, lo) x W^T(hi, lo), weights in LDS as
 // [k-step s][fb][hi | lo][lane] x 16 bytes
 // SPLIT = false (AMBER_PREC_F16): plain fp16 operands, the hi terms only - one MFMA a product (tolerance 1e-2)
-template <int L, bool SPLIT>
+// GROUP feature blocks at a time: GROUP = 2 keeps half the B-operand registers in flight (16 instead of 32 at L = 128), which is
+// what lets the edge kernel hold the rows of e through the hidden layer without spilling; the node kernel keeps 4
+template <int L, bool SPLIT, int GROUP>
 DEVINL void kstep(Tile<L>& acc, const half8 ah, const half8 al, const unsigned char* wl, int s, int lane) {
   constexpr int NFB = L / 32;
+  constexpr int G = NFB < GROUP ? NFB : GROUP;
   const half8* w = reinterpret_cast<const half8*>(wl) + lane;
-  half8 bh[NFB], bl[NFB];
 #pragma unroll
-  for (int fb = 0; fb < NFB; ++fb) {
-    bh[fb] = w[((s * NFB + fb) * 2 + 0) * 64];
-    if constexpr (SPLIT) bl[fb] = w[((s * NFB + fb) * 2 + 1) * 64];
-  }
+  for (int f0 = 0; f0 < NFB; f0 += G) {
+    half8 bh[G], bl[G];
 #pragma unroll
-  for (int fb = 0; fb < NFB; ++fb) acc.a[fb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[fb], acc.a[fb], 0, 0, 0);
-  if constexpr (SPLIT) {
+    for (int g = 0; g < G; ++g) {
+      bh[g] = w[((s * NFB + f0 + g) * 2 + 0) * 64];
+      if constexpr (SPLIT) bl[g] = w[((s * NFB + f0 + g) * 2 + 1) * 64];
+    }
 #pragma unroll
-    for (int fb = 0; fb < NFB; ++fb) acc.a[fb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[fb], acc.a[fb], 0, 0, 0);
+    for (int g = 0; g < G; ++g) acc.a[f0 + g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[g], acc.a[f0 + g], 0, 0, 0);
+    if constexpr (SPLIT) {
 #pragma unroll
-    for (int fb = 0; fb < NFB; ++fb) acc.a[fb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[fb], acc.a[fb], 0, 0, 0);
+      for (int g = 0; g < G; ++g) acc.a[f0 + g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[g], acc.a[f0 + g], 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < G; ++g) acc.a[f0 + g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[g], acc.a[f0 + g], 0, 0, 0);
+    }
   }
 }
 
@@ -334,7 +346,7 @@ struct NoPassHook {
 };
 // `after(ps)` runs when pass ps has left its source registers (la.v[ps] / in.a[ps]): the place to issue loads that may
 // land in them, under the pass's MFMAs
-template <int L, bool SPLIT, bool PIN = false, typename F = NoPassHook>
+template <int L, bool SPLIT, bool PIN = false, int GROUP = AMBER_KSTEP_GROUP_NODE, typename F = NoPassHook>
 DEVINL void gemm_rows(Tile<L>& acc, const ELanding<L>& la, float scale, unsigned char* win, const WinOff& o_in,
                       const unsigned char* wl, int lane, F&& after = NoPassHook()) {
   WinOff o = o_in;
@@ -360,14 +372,14 @@ DEVINL void gemm_rows(Tile<L>& acc, const ELanding<L>& la, float scale, unsigned
       const half8 ah = *reinterpret_cast<const half8*>(win + o.er(sp));
       half8 al = ah;
       if constexpr (SPLIT) al = *reinterpret_cast<const half8*>(win + kLoPlane + o.er(sp));
-      kstep<L, SPLIT>(acc, ah, al, wl, 2 * ps + sp, lane);
+      kstep<L, SPLIT, GROUP>(acc, ah, al, wl, 2 * ps + sp, lane);
     }
   }
 }
 
 // acc += (tile * scale) x W^T for a tile in accumulator layout (feature per lane): 32 features a pass go through the
 // window as a [feature][row] image and come back as the A operand through the transposing read
-template <int L, bool SPLIT, bool PIN = false, typename F = NoPassHook>
+template <int L, bool SPLIT, bool PIN = false, int GROUP = AMBER_KSTEP_GROUP_NODE, typename F = NoPassHook>
 DEVINL void gemm_acc(Tile<L>& acc, const Tile<L>& in, float scale, unsigned char* win, const WinOff& o_in,
                      const unsigned char* wl, int lane, F&& after = NoPassHook()) {
   WinOff o = o_in;
@@ -411,7 +423,7 @@ DEVINL void gemm_acc(Tile<L>& acc, const Tile<L>& in, float scale, unsigned char
           al[4 + t] = b1[t];
         }
       }
-      kstep<L, SPLIT>(acc, ah, al, wl, 2 * fb + sp, lane);
+      kstep<L, SPLIT, GROUP>(acc, ah, al, wl, 2 * fb + sp, lane);
     }
   }
 }
@@ -548,22 +560,13 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
   // so their latency runs under that work.  Measured at L = 64: -2.4 % per launch (L = 32: +30 %, off).  At L = 128 the 64 loop-carried
   // registers do not fit beside the accumulators (the kernel spills, and every scratch reload drains the in-order
   // memory counter, prefetch included: +50 %), so the wide kernel keeps the loads at the top of the tile.
-  constexpr bool PIPE = !EMB && L == 64 && edge_waves<L>() == 8;
-  ELanding<L> la;  // rows of e of the tile at hand: la.v[pass][it] = e[row it*8 + lane/8][32 pass + 4 (lane % 8) .. +3]
+  constexpr bool PIPE = false;
+  // The rows of e arrive ONCE, in accumulator layout (register i of half h = position 16 h + i, a lane's NFB features of it
+  // as one piece): they feed the first contraction through the [feature][edge] window image like a hidden activation
+  // (W0e is packed with the permuted k order for that) and stay in their registers for the residual e + MLP(...), which
+  // round 1 / 2 re-read feature per lane - by then the rows had left the L2: 5 GB of a launch's 18.7 GB of traffic.
+  Tile<L> et;      // e of the tile at hand
   Tile<L> pn;      // P_s[src] of the tile at hand, accumulator layout (becomes the accumulator)
-  auto load_e = [&](int64_t t) {
-    const int64_t q0 = t * kTile;
-    const int lim = ((a.E - q0) < kTile ? static_cast<int>(a.E - q0) : kTile) - 1;
-    const float* const base = a.e + q0 * L;
-    const int rb = 16 * h + ((lane >> 3) & 3);  // operand row it * 8 + lane / 8 holds position 16 h + 4 it + (lane / 8) % 4
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int r = rb + 4 * it;
-      const f32x4* p = reinterpret_cast<const f32x4*>(base + static_cast<unsigned>((r < lim ? r : lim) * L)) + (lane & 7);
-#pragma unroll
-      for (int ps = 0; ps < NFB; ++ps) la.v[ps][it] = p[ps * 8];
-    }
-  };
   auto gather_ps = [&](int sidx, int nq) {
     const float* const psn = a.Ps + NFB * nq;
 #pragma unroll
@@ -574,7 +577,6 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
       tile_set_piece<L>(pn, i, pc);
     }
   };
-  if (PIPE && tile < t_end) load_e(tile);
 #ifdef AMBER_STAMPS
   unsigned st_acc[kStamps] = {};
   unsigned st_tiles = 0;
@@ -587,7 +589,7 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
 #endif
     const int64_t p0 = tile * kTile;
     const int nvalid = (a.E - p0) < kTile ? static_cast<int>(a.E - p0) : kTile;  // >= 1: tile < ntiles
-    float* const et = a.e + p0 * L;     // this tile's rows of e (wave-uniform base, 32-bit lane offsets)
+    const float* const et_rows = a.e + p0 * L;  // this tile's rows of e (wave-uniform base, 32-bit lane offsets)
     float* const eo = (a.e_out ? a.e_out : a.e) + p0 * L;  // where the updated rows go (training tape: not in place)
     const int rlim = nvalid - 1;
     // Lane offsets of the direct row accesses are recomputed per tile from these opaque copies: hoisted out of the tile
@@ -661,10 +663,19 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
       if (p > a.E - 1) p = a.E - 1;
       pm = a.perm[p];
     }
-    if constexpr (!EMB && !PIPE) load_e(tile);
+    if constexpr (!EMB) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        float pc[NFB];
+        if (nvalid == kTile)  // one address per group of rows, rows inside it are immediate offsets
+          piece_load<L>(et_rows + static_cast<unsigned>(hq) + kRowGroup<L> * (i / kRowGroup<L>) * L + (i % kRowGroup<L>) * L, pc);
+        else  // rows beyond the end repeat the last edge and are never stored
+          piece_load<L>(et_rows + static_cast<unsigned>(min(i + 16 * h, rlim) * L + NFB * nq), pc);
+        tile_set_piece<L>(et, i, pc);
+      }
+    }
     gather_ps(sx0, nq);
     Tile<L> acc = pn;
-    if (tile + stride < t_end) load_idx(tile + stride, sx1, d1, dx1);
     // The per-destination sums run per HALF over its own sixteen positions (reduction tiles of 16 edges, red_shift 4):
     // first / last destination of this half's positions and where their rows begin / end
     const int nvh = nvalid - 16 * h < 0 ? 0 : (nvalid - 16 * h > 16 ? 16 : nvalid - 16 * h);  // positions of this half that exist
@@ -686,7 +697,7 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
     if constexpr (EMB) {
       fold_tile_add(acc);  // exact fp32, no scaled domain
     } else {
-      pow2_scale(wave_max(landing_absmax<L>(la)), scale, inv);
+      pow2_scale(wave_max(tile_absmax<L>(et)), scale, inv);
       STAMP(2);  // e rows arrived, tile maximum
       tile_scale<L>(acc, scale * wscale0);
       STAMP(3);  // P_s rows arrived
@@ -709,13 +720,9 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
 #pragma unroll
       for (int ps = 0; ps < NFB; ++ps) load_pd(ps);
     } else {
-#ifdef AMBER_PREFETCH_PD
-      if (!DBG(8)) gemm_rows<L, SPLIT>(acc, la, scale, win, wo, smem, lane, load_pd);
-#else
-      if (!DBG(8)) gemm_rows<L, SPLIT>(acc, la, scale, win, wo, smem, lane);
+      if (!DBG(8)) gemm_acc<L, SPLIT, true, AMBER_KSTEP_GROUP>(acc, et, scale, win, wo, smem, lane);
 #pragma unroll
       for (int ps = 0; ps < NFB; ++ps) load_pd(ps);
-#endif
       us = inv * wsinv0;
     }
     STAMP(4);  // layer 0 contraction
@@ -733,34 +740,19 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
     asm volatile("" : "+v"(sb_i), "+v"(ends_last_i));  // evaluated HERE, not sunk to the point of use
     STAMP(5);  // P_d rows, activation
     // ---- hidden layers: the activations go through the window as a [feature][edge] image ----
-    // The residual rows of e (this wave's own loads of the tile's top, by now in L2 at best).  Fetching them under the
-    // last hidden layer's contraction, a quarter of the tile after every pass into the registers of the layer's input that
-    // the pass has just left (AMBER_PREFETCH_RES), is register-neutral on paper; the compiler spills 70 - 260 registers
-    // over it, so they are fetched after the layer.
     const bool res_rows = !EMB && a.residual == AMBER_MODE_INNER && !DBG(1);
-    float resp[16][NFB];
-    auto load_res = [&](int ps) {
-#pragma unroll
-      for (int j = 0; j < 16 / NFB; ++j) {
-        const int i = (16 / NFB) * ps + j;
-        if (nvalid == kTile)
-          piece_load<L>(et + static_cast<unsigned>(hq) + kRowGroup<L> * (i / kRowGroup<L>) * L + (i % kRowGroup<L>) * L, resp[i]);
-        else  // rows beyond the end repeat the last edge
-          piece_load<L>(et + static_cast<unsigned>(min(i + 16 * h, rlim) * L + NFB * n), resp[i]);
-      }
-    };
     // one hidden layer: acc <- act(W_l acc + b_l); `hook(ps)` as in gemm_acc
     auto hidden_layer = [&](int l, auto&& hook) {
       const float* wg = a.layers[l].w;
       float bv[NFB];
-      piece_load<L>(a.layers[l].b + NFB * n, bv);  // ahead of the residual rows in the in-order queue
+      piece_load<L>(a.layers[l].b + NFB * nq, bv);
       pow2_scale(wave_max(tile_absmax<L>(acc)), scale, inv);
       // accumulate from zero (the first MFMA of a block takes the constant 0 as its C operand: no 64 moves to seed the
       // accumulators) and add the bias with the multiply that takes the result back out of the scaled domain
       Tile<L> nxt;
       tile_zero<L>(nxt);
       if (!DBG(8)) {
-        gemm_acc<L, SPLIT>(nxt, acc, scale, win, wo, smem + l * MAT_BYTES, lane, hook);
+        gemm_acc<L, SPLIT, true, AMBER_KSTEP_GROUP>(nxt, acc, scale, win, wo, smem + l * MAT_BYTES, lane, hook);
       } else {
 #pragma unroll
         for (int ps = 0; ps < NFB; ++ps) hook(ps);
@@ -776,20 +768,10 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
     };
 #pragma unroll 1
     for (int l = 1; l < a.nl - 1; ++l) hidden_layer(l, NoPassHook());
-#ifdef AMBER_PREFETCH_RES
-    // (the last hidden layer apart from the loop: only it fetches, and inside the loop the fetched rows would be live
-    // through every layer)
-    if (a.nl > 1) {
-      hidden_layer(a.nl - 1, [&](int ps) {
-        if (res_rows) load_res(ps);
-      });
-    } else if (res_rows) {
-#pragma unroll
-      for (int ps = 0; ps < NFB; ++ps) load_res(ps);
-    }
-#else
     if (a.nl > 1) hidden_layer(a.nl - 1, NoPassHook());
-#endif
+    // the next tile's indices: fetched here, ahead of this tile's stores (a load behind them would wait for them to drain)
+    // and after the contractions, whose registers they would otherwise share
+    if (tile + stride < t_end) load_idx(tile + stride, sx1, d1, dx1);
     STAMP(6);  // hidden layers
     // ---- residual: the rows of e again (this wave's own loads of a moment ago), now feature per lane ----
     if (EMB && a.residual == AMBER_MODE_INNER) {
@@ -797,24 +779,15 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
       embed_tile(e0);
       tile_add<L>(acc, e0);
     } else if (res_rows) {
-#ifndef AMBER_PREFETCH_RES
-#pragma unroll
-      for (int ps = 0; ps < NFB; ++ps) load_res(ps);
-#endif
-#pragma unroll
-      for (int i = 0; i < 16; ++i)
-#pragma unroll
-        for (int fb = 0; fb < NFB; ++fb) acc.a[fb][i] += resp[i][fb];
-    }
-    if constexpr (PIPE) {  // the next tile's opening loads, behind which the rest of this tile runs
-      __builtin_amdgcn_sched_barrier(0);  // not above the residual loads: their landing registers are free only now
-      if (tile + stride < t_end) load_e(tile + stride);
-      __builtin_amdgcn_sched_barrier(0);
+      tile_add<L>(acc, et);  // the rows of e, still in their registers
     }
     STAMP(7);  // residual
     // ---- LayerNorm over the features of every edge: across the lanes of a half, one register per edge ----
-    if (a.layer_norm == AMBER_MODE_INNER && !DBG(64)) tile_layernorm_acc<L>(acc, a.gamma, a.beta, a.eps, n);
+    if (a.layer_norm == AMBER_MODE_INNER && !DBG(64)) tile_layernorm_acc<L>(acc, a.gamma, a.beta, a.eps, nq);
     STAMP(8);  // LayerNorm
+    // (the addresses of the stores and partial sums are formed from here on: derived at the tile's top from the same lane
+    // offsets they are live - and spilled - across both contractions)
+    asm volatile("" : "+v"(hq), "+v"(nq));
     // ---- stores of e' (two whole 128-byte row pieces per register) ----
     if (a.write_e || a.out_edge) {
       if (a.write_e && !DBG(16)) {
@@ -848,7 +821,7 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
           if (r < nvalid) {
             float pc[NFB];
             tile_get_piece<L>(acc, i, pc);
-            piece_store<L>(a.out_edge + static_cast<size_t>(orow) * L + NFB * n, pc);
+            piece_store<L>(a.out_edge + static_cast<size_t>(orow) * L + NFB * nq, pc);
           }
         }
       }
