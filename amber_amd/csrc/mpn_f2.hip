@@ -53,6 +53,9 @@ constexpr int kStamps = 12;
 #define STAMP(k)
 #endif
 
+#ifndef AMBER_EDGE_PREFETCH_E
+#define AMBER_EDGE_PREFETCH_E 1
+#endif
 #ifndef AMBER_KSTEP_GROUP_NODE
 #define AMBER_KSTEP_GROUP_NODE 2
 #endif
@@ -577,6 +580,26 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
       tile_set_piece<L>(pn, i, pc);
     }
   };
+  // rows of e of tile t into `et` (accumulator layout).  With AMBER_EDGE_PREFETCH_E the NEXT tile's rows are fetched as soon
+  // as the residual has taken the current ones - et's registers are free from there to the tile's end - ahead of this
+  // tile's stores, so that the tile's top issues half as many loads and never waits for them behind the stores.
+  auto load_et = [&](int64_t t, int hq_, int nq_) {
+    const int64_t q0 = t * kTile;
+    const int nv = (a.E - q0) < kTile ? static_cast<int>(a.E - q0) : kTile;
+    const float* const rows = a.e + q0 * L;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      float pc[NFB];
+      if (nv == kTile)  // one address per group of rows, rows inside it are immediate offsets
+        piece_load<L>(rows + static_cast<unsigned>(hq_) + kRowGroup<L> * (i / kRowGroup<L>) * L + (i % kRowGroup<L>) * L, pc);
+      else  // rows beyond the end repeat the last edge and are never stored
+        piece_load<L>(rows + static_cast<unsigned>(min(i + 16 * h, nv - 1) * L + NFB * nq_), pc);
+      tile_set_piece<L>(et, i, pc);
+    }
+  };
+  if constexpr (!EMB && AMBER_EDGE_PREFETCH_E != 0) {
+    if (tile < t_end) load_et(tile, 16 * h * L + NFB * n, n);
+  }
 #ifdef AMBER_STAMPS
   unsigned st_acc[kStamps] = {};
   unsigned st_tiles = 0;
@@ -663,17 +686,7 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
       if (p > a.E - 1) p = a.E - 1;
       pm = a.perm[p];
     }
-    if constexpr (!EMB) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        float pc[NFB];
-        if (nvalid == kTile)  // one address per group of rows, rows inside it are immediate offsets
-          piece_load<L>(et_rows + static_cast<unsigned>(hq) + kRowGroup<L> * (i / kRowGroup<L>) * L + (i % kRowGroup<L>) * L, pc);
-        else  // rows beyond the end repeat the last edge and are never stored
-          piece_load<L>(et_rows + static_cast<unsigned>(min(i + 16 * h, rlim) * L + NFB * nq), pc);
-        tile_set_piece<L>(et, i, pc);
-      }
-    }
+    if constexpr (!EMB && AMBER_EDGE_PREFETCH_E == 0) load_et(tile, hq, nq);
     gather_ps(sx0, nq);
     Tile<L> acc = pn;
     // The per-destination sums run per HALF over its own sixteen positions (reduction tiles of 16 edges, red_shift 4):
@@ -781,6 +794,8 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
     } else if (res_rows) {
       tile_add<L>(acc, et);  // the rows of e, still in their registers
     }
+    if constexpr (!EMB && AMBER_EDGE_PREFETCH_E != 0)  // (no branch: the last tile fetches its own rows again, unread)
+      load_et(tile + stride < t_end ? tile + stride : tile, hq, nq);
     STAMP(7);  // residual
     // ---- LayerNorm over the features of every edge: across the lanes of a half, one register per edge ----
     if (a.layer_norm == AMBER_MODE_INNER && !DBG(64)) tile_layernorm_acc<L>(acc, a.gamma, a.beta, a.eps, nq);
