@@ -53,6 +53,9 @@ constexpr int kStamps = 12;
 #define STAMP(k)
 #endif
 
+#ifndef AMBER_EDGE_PD_EARLY
+#define AMBER_EDGE_PD_EARLY 1
+#endif
 #ifndef AMBER_EDGE_PREFETCH_E
 #define AMBER_EDGE_PREFETCH_E 1
 #endif
@@ -733,9 +736,15 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
 #pragma unroll
       for (int ps = 0; ps < NFB; ++ps) load_pd(ps);
     } else {
+#if AMBER_EDGE_PD_EARLY
+#pragma unroll
+      for (int ps = 0; ps < NFB; ++ps) load_pd(ps);
+      if (!DBG(8)) gemm_acc<L, SPLIT, true, AMBER_KSTEP_GROUP>(acc, et, scale, win, wo, smem, lane);
+#else
       if (!DBG(8)) gemm_acc<L, SPLIT, true, AMBER_KSTEP_GROUP>(acc, et, scale, win, wo, smem, lane);
 #pragma unroll
       for (int ps = 0; ps < NFB; ++ps) load_pd(ps);
+#endif
       us = inv * wsinv0;
     }
     STAMP(4);  // layer 0 contraction
