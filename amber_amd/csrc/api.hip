@@ -213,9 +213,9 @@ Workspace carve(const AmberMpnDesc& d, int64_t N, int64_t E, void* base) {
   return w;
 }
 
-// training tape: block inputs of every step, x_t[N,L] and e_t[E,L] (CSR order), t = 0 .. iters; with an "outer" residual /
-// LayerNorm also the mean aggregate m_t[N,L] of every step (the node module aggregates the edge module's output BEFORE the
-// outer residual / LayerNorm, which is not the e_{t+1} of the tape)
+// training tape: block inputs of every step, x_t[N,L] and e_t[E,L] (CSR order), t = 0 .. iters, and the mean aggregate
+// m_t[N,L] of every step as the forward's node kernel formed it (with an "outer" residual / LayerNorm the node module
+// aggregates the edge module's output BEFORE them, which is not the e_{t+1} of the tape)
 struct Tape {
   float *x, *e, *m;
   size_t bytes;
@@ -228,11 +228,10 @@ Tape carve_tape(const AmberMpnDesc& d, int64_t N, int64_t E, float* base) {
   const size_t xb = align256(sizeof(float) * T1 * static_cast<size_t>(N) * L);
   t.e = reinterpret_cast<float*>(reinterpret_cast<char*>(base) + xb);
   t.bytes = xb + align256(sizeof(float) * T1 * static_cast<size_t>(E) * L);
-  t.m = nullptr;
-  if (has_outer_mode(d)) {
-    t.m = reinterpret_cast<float*>(reinterpret_cast<char*>(base) + t.bytes);
-    t.bytes += align256(sizeof(float) * (T1 - 1) * static_cast<size_t>(N) * L);
-  }
+  // the mean aggregate of every step: with an "outer" mode it is not a function of e_{t+1} at all, and otherwise keeping what
+  // the forward's node kernel used (N rows a step) is cheaper than summing the E rows of e_{t+1} again in the backward
+  t.m = reinterpret_cast<float*>(reinterpret_cast<char*>(base) + t.bytes);
+  t.bytes += align256(sizeof(float) * (T1 - 1) * static_cast<size_t>(N) * L);
   return t;
 }
 
@@ -799,10 +798,8 @@ int backward_impl(const AmberMpnDesc* desc, const float* params, const float* pa
     }
     // ---- node module: x' = LN(MLP([x, mean(e')]) + x) ----
     const float* mean_in = w.M;
-    if (tp.m)  // outer modes: the aggregate of the edge module's output before the outer residual / LayerNorm, kept by the forward
+    if (E > 0)  // the aggregate the forward's node kernel used, kept on the tape
       mean_in = tp.m + static_cast<size_t>(it) * NL;
-    else if (E > 0)
-      HIP_TRY(launch_segment_reduce(ebuf(it + 1), rowptr, nullptr, N, L, 1, w.M, s), "mean aggregate");
     else
       HIP_TRY(hipMemsetAsync(w.M, 0, sizeof(float) * NL, s), "clear M");
     {

@@ -215,9 +215,8 @@ int amber_mpn_forward_timed(const AmberMpnDesc* desc, const float* params, const
  * loss.backward() on the output of SupervisedMPN.forward).
  *
  * amber_mpn_forward_train = amber_mpn_forward that additionally keeps the block inputs of every step on a
- * caller-owned TAPE (x_t[N,L], e_t[E,L] in CSR order, t = 0 .. num_steps * num_step_repeats; with an "outer" residual
- * or LayerNorm also the mean aggregate m_t[N,L] of every step, which then is not a function of e_{t+1};
- * amber_mpn_tape_bytes).  amber_mpn_backward recomputes each module from its tape entry (activation checkpointing
+ * caller-owned TAPE (x_t[N,L], e_t[E,L] in CSR order, t = 0 .. num_steps * num_step_repeats, and the mean aggregate
+ * m_t[N,L] of every step as the forward formed it; amber_mpn_tape_bytes).  amber_mpn_backward recomputes each module from its tape entry (activation checkpointing
  * per block) and writes the gradient of every parameter, in the layout of `params`, to grad_params
  * (amber_mpn_param_floats floats, overwritten).  Gradients arrive as any of
  *   grad_sizing[N_m] (needs has_head), grad_node[N,L], grad_edge[E,L] (edge_index order); NULL = zero.

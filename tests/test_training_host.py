@@ -76,7 +76,8 @@ def test_training_size_queries_and_validation():
     n, e = 1000, 7000
     a256 = lambda b: (b + 255) // 256 * 256  # noqa: E731
     t1 = 3 * 2 + 1  # block inputs of every step application + the final state
-    assert lib.amber_mpn_tape_bytes(C.byref(d), n, e) == a256(t1 * n * 64 * 4) + a256(t1 * e * 64 * 4) + 256
+    # ... and the mean aggregate of every step application
+    assert lib.amber_mpn_tape_bytes(C.byref(d), n, e) == a256(t1 * n * 64 * 4) + a256(t1 * e * 64 * 4) + a256((t1 - 1) * n * 64 * 4) + 256
     assert lib.amber_mpn_backward_workspace_bytes(C.byref(d), n, e) >= lib.amber_mpn_workspace_bytes(C.byref(d), n, e)
     # configurations the backward kernels do not take are refused by name, before any pointer is touched
     for bad, word in ((dict(decoder_activation="gelu"), b"decoder activation"), (dict(decoder_norm="batch"), b"BatchNorm"),
@@ -84,9 +85,6 @@ def test_training_size_queries_and_validation():
         db = engine.make_desc(**{**kw, **bad})
         rc = lib.amber_mpn_forward_train(C.byref(db), 0, 0, n, e, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0)
         assert rc == -2 and word in lib.amber_mpn_last_error()
-    # an "outer" residual / LayerNorm also keeps the mean aggregate of every step application on the tape
-    do = engine.make_desc(**{**kw, "residual": "outer"})
-    assert lib.amber_mpn_tape_bytes(C.byref(do), n, e) == a256(t1 * n * 64 * 4) + a256(t1 * e * 64 * 4) + a256((t1 - 1) * n * 64 * 4) + 256
     # MLP embeddings and the decoder's LayerNorm need row buffers of their own
     dm = engine.make_desc(**{**kw, "embed_layers": 4, "decoder_norm": "layer"})
     assert lib.amber_mpn_backward_workspace_bytes(C.byref(dm), n, e) > lib.amber_mpn_backward_workspace_bytes(C.byref(d), n, e)
