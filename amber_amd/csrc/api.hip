@@ -602,7 +602,6 @@ int forward_impl(const AmberMpnDesc* desc, const float* params, const float* pac
 // training: configurations the backward kernels take, workspace, and the launch sequence
 // ---------------------------------------------------------------------------------------------------
 int validate_train(const AmberMpnDesc& d) {
-  if (d.latent > 128) return fail(AMBER_ERR_UNSUPPORTED, "training: latent_dimension %d is not built (32, 64, 128 are)", d.latent);
   if (d.has_head) {
     if (d.decoder_activation > AMBER_ACT_TANH)
       return fail(AMBER_ERR_UNSUPPORTED, "training: decoder activation id %d (relu, leakyrelu, tanh only)", d.decoder_activation);

@@ -800,6 +800,7 @@ hipError_t launch_chain_bwd(int L, const ChainBwdArgs& a, hipStream_t s) {
     case 32: return launch_chain_bwd_t<32>(a, s);
     case 64: return launch_chain_bwd_t<64>(a, s);
     case 128: return launch_chain_bwd_t<128>(a, s);
+    case 256: return launch_chain_bwd_t<256>(a, s);
     default: return hipErrorInvalidValue;
   }
 }
@@ -893,6 +894,7 @@ hipError_t launch_wgrad_batch(int L, const WgradBatch& b, float* part, float* cp
     case 32: return launch_wgrad_t<32>(b, part, cpart, s);
     case 64: return launch_wgrad_t<64>(b, part, cpart, s);
     case 128: return launch_wgrad_t<128>(b, part, cpart, s);
+    case 256: return launch_wgrad_t<256>(b, part, cpart, s);
     default: return hipErrorInvalidValue;
   }
 }
@@ -959,6 +961,7 @@ hipError_t launch_rows_gemm_add(int L, float* io, const float* in0, const float*
     case 32: return launch_rows_gemm_add_t<32>(io, in0, w0, in1, w1, rows, s);
     case 64: return launch_rows_gemm_add_t<64>(io, in0, w0, in1, w1, rows, s);
     case 128: return launch_rows_gemm_add_t<128>(io, in0, w0, in1, w1, rows, s);
+    case 256: return launch_rows_gemm_add_t<256>(io, in0, w0, in1, w1, rows, s);
     default: return hipErrorInvalidValue;
   }
 }
@@ -990,6 +993,7 @@ hipError_t launch_pack_t(int L, const float* W, int ld, int col0, float* out, hi
     case 32: return launch_pack_t_t<32>(W, ld, col0, out, s);
     case 64: return launch_pack_t_t<64>(W, ld, col0, out, s);
     case 128: return launch_pack_t_t<128>(W, ld, col0, out, s);
+    case 256: return launch_pack_t_t<256>(W, ld, col0, out, s);
     default: return hipErrorInvalidValue;
   }
 }

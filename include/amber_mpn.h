@@ -71,7 +71,7 @@ enum {
  * config/algorithm/architecture/mpn.yaml ("Config / flags"). */
 typedef struct AmberMpnDesc {
   int32_t latent;             /* latent_dimension: 32, 64, 128, or 256 (256: exact fp32 kernels in every precision mode,
-                                 inference only) */
+                                 forward and backward) */
   int32_t num_steps;          /* stack.num_steps: blocks with their own weights */
   int32_t num_step_repeats;   /* stack.num_step_repeats: each block applied this often */
   int32_t mlp_layers;         /* stack.mlp.num_layers, 1..AMBER_MPN_MAX_MLP_LAYERS */
@@ -224,10 +224,10 @@ int amber_mpn_forward_timed(const AmberMpnDesc* desc, const float* params, const
  * rowptr_src / perm_src: the SOURCE-sorted order of the CSR positions, i.e. amber_mpn_csr_build applied to the
  * edge list [dst_sorted ; src_sorted] (its rowptr and perm outputs) -- used for the deterministic per-source sums.
  * Edge dropout (src/mpn/common/edge_dropout.py:24-25) happens before the call: the caller passes the kept edges.
- * Built for: latent 32 / 64 / 128; residual / layer_norm none, inner or outer (message_passing_block.py:62-74,91-97);
+ * Built for: every latent width of the forward (256: exact fp32 kernels, correct and slow); residual / layer_norm none, inner or outer (message_passing_block.py:62-74,91-97);
  * constant, linear or LatentMLP embeddings (embedding.py:32-38); decoder activations relu / leakyrelu / tanh with
- * latent_normalization none or layer (mlp.py:86-93).  Decoder BatchNorm, the other decoder activations and latent 256
- * return AMBER_ERR_UNSUPPORTED.
+ * latent_normalization none or layer (mlp.py:86-93).  Decoder BatchNorm and the other decoder activations return
+ * AMBER_ERR_UNSUPPORTED.
  * ------------------------------------------------------------------------------------------------- */
 size_t amber_mpn_tape_bytes(const AmberMpnDesc* desc, int64_t num_nodes, int64_t num_edges);
 int amber_mpn_forward_train(const AmberMpnDesc* desc, const float* params, const float* packed, int64_t num_nodes,

@@ -453,6 +453,24 @@ def test_decoder_layernorm_gradients_match_oracle(gpu_device, dec_layers, latent
         _check_grads_kink_aware(model, want, flips)
 
 
+def test_latent_256_gradients_match_oracle(gpu_device):
+    """The upper end of north_star's width range trains as well (exact fp32 kernels, like its forward): hub rows longer than a
+    tile, zero in-degree nodes, a partial mask."""
+    rng = np.random.default_rng(41)
+    el, n, mask = syn.hierarchical_graph(14, 11, 2, 2, rng)
+    g = syn.make_batch([el], [n], 4, 2, seed=5, mask_outputs=[mask])
+    cfg = _cfg(256, 2, act="tanh")
+    params = orc.init_params(cfg, seed=9)
+    d = dict(x=g.x, edge_attr=g.edge_attr, edge_index=g.edge_index, batch=g.batch, mask_output=g.mask_output)
+    grad_out = torch.randn(int(g.mask_output.sum()), 1, generator=torch.Generator().manual_seed(9))
+    model = _model(cfg, params, d, gpu_device).train()
+    out = model(_batch(d, gpu_device))
+    (out * grad_out.to(gpu_device)).sum().backward()
+    want_out, want = _oracle_grads(cfg, params, g.x, g.edge_attr, g.edge_index, g.mask_output, grad_out)
+    assert close(out.detach().cpu(), want_out)
+    _check_grads(model, want, GRAD_TOL)
+
+
 def test_unsupported_training_configurations_raise(gpu_device):
     """What the backward is not built for raises instead of returning wrong gradients: decoder activations beyond relu /
     leakyrelu / tanh (their derivative needs the pre-activation, which the tape does not keep)."""
