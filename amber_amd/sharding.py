@@ -174,3 +174,24 @@ def sharded_forward(forward_fn: Callable, batch, rank: int, world_size: int, gat
             pieces[g] = o[off:off + kept[g]]
             off += kept[g]
     return torch.cat([p for p in pieces if p is not None], dim=0).to(dev)
+
+
+def broadcast_buffers(module: torch.nn.Module, src: int = 0, group=None) -> None:
+    """Make rank `src`'s buffers of `module` (the running statistics of the normalisers, a decoder's BatchNorm running
+    buffers) the buffers of every rank, in place.  The statistics are updated on the host from each rank's own new data
+    (/root/reference/src/algorithm/core/amber.py:335); with graph-wise data parallelism one rank stays authoritative and
+    the others take its numbers, so that every rank normalises its shard identically.  A no-op
+    without an initialised process group or with one rank.  Device tensors under gloo are staged through the host (see
+    engine._sync_flat_gradient); RCCL takes them as they are."""
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    gloo = dist.get_backend(group) == "gloo"
+    for buf in module.buffers():
+        if buf.is_cuda and gloo:
+            host = buf.detach().cpu()
+            dist.broadcast(host, src=src, group=group)
+            buf.copy_(host)
+        else:
+            dist.broadcast(buf, src=src, group=group)

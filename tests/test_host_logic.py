@@ -247,3 +247,35 @@ def test_world_size_2_sharded_forward_equals_unsharded(name):
     got = ret["out"]
     assert got.shape == want.shape
     assert float((got - want).abs().max() / want.abs().max()) <= 2e-6
+
+
+def _stats_worker(rank, world, port, ret):
+    import torch.distributed as dist
+
+    from amber_amd.normalizer.torch_running_mean_std import TorchRunningMeanStd
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    stats = TorchRunningMeanStd(epsilon=1e-4, shape=(3,))
+    gen = torch.Generator().manual_seed(100 + rank)
+    stats.update(torch.randn(50, 3, generator=gen, dtype=torch.float64) * (rank + 1))  # every rank saw other data
+    mine = (stats.mean.clone(), stats.var.clone(), stats.count.clone())
+    sharding.broadcast_buffers(stats, src=0)
+    ret[rank] = (mine, (stats.mean.clone(), stats.var.clone(), stats.count.clone()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world_size_2_broadcast_of_normaliser_statistics():
+    """Rank 0's running statistics become every rank's (rank 0 authoritative), bit for bit; and without a process
+    group the call does nothing."""
+    from amber_amd.normalizer.torch_running_mean_std import TorchRunningMeanStd
+
+    lone = TorchRunningMeanStd(epsilon=1e-4, shape=(2,))
+    sharding.broadcast_buffers(lone)  # no process group: a no-op
+    ret = mp.Manager().dict()
+    mp.spawn(_stats_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    (own0, after0), (own1, after1) = ret[0], ret[1]
+    assert not torch.equal(own0[0], own1[0])  # the ranks did differ
+    for a, b, c in zip(own0, after0, after1):
+        assert torch.equal(a, b) and torch.equal(a, c)
