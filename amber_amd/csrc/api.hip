@@ -280,8 +280,11 @@ struct Timer {
 // Debug switches of the environment, read ONCE per process: the packed-buffer layout depends on them (use_fast_head), so
 // a value that changed between amber_mpn_pack_weights and a forward would make the kernels read the wrong matrices.
 struct EnvSwitches {
-  bool no_fused_head, no_fused_embed;
-  EnvSwitches() : no_fused_head(getenv("AMBER_MPN_NO_FUSED_HEAD") != nullptr), no_fused_embed(getenv("AMBER_MPN_NO_FUSED_EMBED") != nullptr) {}
+  bool no_fused_head, no_fused_embed, exact_backward;
+  EnvSwitches()
+      : no_fused_head(getenv("AMBER_MPN_NO_FUSED_HEAD") != nullptr),
+        no_fused_embed(getenv("AMBER_MPN_NO_FUSED_EMBED") != nullptr),
+        exact_backward(getenv("AMBER_MPN_EXACT_BACKWARD") != nullptr) {}
 };
 const EnvSwitches& env_switches() {
   static const EnvSwitches e;
@@ -297,6 +300,10 @@ int dbg_switches() {
 #endif
 }
 
+// the backward's contractions on bf16x3 operands (mpn_bwd.hip) unless the descriptor asks for exact fp32 arithmetic
+bool use_split_backward(const AmberMpnDesc& d) {
+  return d.precision != AMBER_PREC_FP32 && bwd_split_supported(d.latent) && !env_switches().exact_backward;
+}
 bool use_fast_edge(const AmberMpnDesc& d) {
   return d.precision != AMBER_PREC_FP32 && edge_f2_supported(d.latent, d.mlp_layers, d.activation, d.residual, d.layer_norm);
 }
@@ -662,7 +669,7 @@ BwdWorkspace carve_bwd(const AmberMpnDesc& d, int64_t N, int64_t E, void* base) 
   w.lnpart = take(align256(sizeof(float) * kBwdMaxBlocks * 2 * L));
   w.pnpart = dnorm ? take(align256(sizeof(float) * kBwdMaxBlocks * kBwdWavesPerBlock * d.decoder_layers * 2 * L)) : nullptr;
   w.epart = take(align256(sizeof(float) * kWgradMaxChunks * L * 65));
-  w.mat_floats = L * L + kPackedHeader;
+  w.mat_floats = bwd_mat_floats(d.latent);
   w.mats = take(align256(sizeof(float) * kBwdMats * w.mat_floats));
   w.bytes = off;
   return w;
@@ -684,6 +691,8 @@ int backward_impl(const AmberMpnDesc* desc, const float* params, const float* pa
   auto ebuf = [&](int t) { return tp.e + static_cast<size_t>(t) * EL; };
   float* const g = grad_params;
   auto mat = [&](int i) { return w.mats + static_cast<size_t>(i) * w.mat_floats; };
+  const int split = use_split_backward(d) ? 1 : 0;
+  const int fmt = split ? AMBER_PACK_B3 : AMBER_PACK_F32;
 
   HIP_TRY(hipMemsetAsync(g, 0, sizeof(float) * static_cast<size_t>(lay.n_params), s), "clear gradients");
   if (N == 0) return AMBER_OK;
@@ -704,6 +713,7 @@ int backward_impl(const AmberMpnDesc* desc, const float* params, const float* pa
     const int nd = d.decoder_layers;
     ChainBwdArgs a{};
     a.mode = AMBER_BWD_HEAD;
+    a.split = split;
     a.rows = N;
     a.rin = xbuf(iters);
     a.nl = nd;
@@ -711,9 +721,15 @@ int backward_impl(const AmberMpnDesc* desc, const float* params, const float* pa
     a.residual = AMBER_MODE_NONE;
     a.layer_norm = AMBER_MODE_NONE;
     a.eps = d.ln_eps;
+    {
+      PackBatch pb{};
+      for (int l = 0; l < nd; ++l) {
+        pb.job[pb.n++] = PackJob{params + lay.dec.W[l], mat(2 * l), L, 0, 0, fmt};
+        pb.job[pb.n++] = PackJob{params + lay.dec.W[l], mat(2 * l + 1), L, 0, 1, fmt};
+      }
+      HIP_TRY(launch_pack_batch(L, pb, s), "pack decoder matrices");
+    }
     for (int l = 0; l < nd; ++l) {
-      HIP_TRY(launch_pack(L, params + lay.dec.W[l], L, 0, mat(2 * l), s), "pack decoder");
-      HIP_TRY(launch_pack_t(L, params + lay.dec.W[l], L, 0, mat(2 * l + 1), s), "pack decoder^T");
       if (l == 0) {
         a.w_in = mat(0);
         a.wT_in = mat(1);
@@ -750,7 +766,7 @@ int backward_impl(const AmberMpnDesc* desc, const float* params, const float* pa
                                               g + lay.dec.P[l], g + lay.dec.Q[l], s),
                 "decoder LayerNorm gradient");
     for (int l = 0; l < nd; ++l)
-      HIP_TRY(launch_wgrad(L, w.DHN[l], l == 0 ? xbuf(iters) : w.AN[l - 1], N, g + lay.dec.W[l], L, 0, g + lay.dec.B[l], w.gpart,
+      HIP_TRY(launch_wgrad(L, split, w.DHN[l], l == 0 ? xbuf(iters) : w.AN[l - 1], N, g + lay.dec.W[l], L, 0, g + lay.dec.B[l], w.gpart,
                            w.cpart, s),
               "decoder weight gradient");
   }
@@ -771,7 +787,7 @@ int backward_impl(const AmberMpnDesc* desc, const float* params, const float* pa
     {
       PackBatch pb{};
       auto pj = [&](const float* W, int ld, int col0, int slot, int transpose) {
-        pb.job[pb.n++] = PackJob{W, mat(slot), ld, col0, transpose};
+        pb.job[pb.n++] = PackJob{W, mat(slot), ld, col0, transpose, fmt};
       };
       pj(params + mn.W[0], 2 * L, 0, 0, 0);
       pj(params + mn.W[0], 2 * L, 0, 1, 1);
@@ -804,6 +820,7 @@ int backward_impl(const AmberMpnDesc* desc, const float* params, const float* pa
     {
       ChainBwdArgs a{};
       a.mode = AMBER_BWD_NODE;
+      a.split = split;
       a.rows = N;
       a.rin = x_in;
       a.m = mean_in;
@@ -834,6 +851,7 @@ int backward_impl(const AmberMpnDesc* desc, const float* params, const float* pa
       HIP_TRY(launch_chain_bwd(L, a, s), "node backward kernel");
       if (ln) HIP_TRY(launch_colpart_reduce(w.lnpart, gn, L, g + lay.ng[step], L, g + lay.nb[step], L, s), "node LayerNorm gradient");
       WgradBatch wb{};
+      wb.split = split;
       wb.M = N;
       wjob(wb, w.DHN[0], x_in, g + mn.W[0], 2 * L, 0, g + mn.B[0]);  // dW0x, db0
       wjob(wb, w.DHN[0], mean_in, g + mn.W[0], 2 * L, L, nullptr);   // dW0a
@@ -850,6 +868,7 @@ int backward_impl(const AmberMpnDesc* desc, const float* params, const float* pa
       HIP_TRY(run_node(d, pa, s), "projection recompute");
       ChainBwdArgs a{};
       a.mode = AMBER_BWD_EDGE;
+      a.split = split;
       a.rows = E;
       a.rin = e_in;
       a.Ps = w.Ps;
@@ -879,6 +898,7 @@ int backward_impl(const AmberMpnDesc* desc, const float* params, const float* pa
       HIP_TRY(launch_chain_bwd(L, a, s), "edge backward kernel");
       if (ln) HIP_TRY(launch_colpart_reduce(w.lnpart, ge, L, g + lay.eg[step], L, g + lay.eb[step], L, s), "edge LayerNorm gradient");
       WgradBatch we{};
+      we.split = split;
       we.M = E;
       wjob(we, w.DHE[0], e_in, g + me.W[0], 3 * L, 2 * L, nullptr);  // dW0e
       for (int l = 1; l < nl; ++l) wjob(we, w.DHE[l], w.AE[l - 1], g + me.W[l], L, 0, g + me.B[l]);
@@ -887,11 +907,12 @@ int backward_impl(const AmberMpnDesc* desc, const float* params, const float* pa
       HIP_TRY(launch_segment_reduce(w.DHE[0], rowptr, nullptr, N, L, 0, w.dPd, s), "dP_d");
       HIP_TRY(launch_segment_reduce(w.DHE[0], rowptr_src, perm_src, N, L, 0, w.dPs, s), "dP_s");
       WgradBatch wp{};
+      wp.split = split;
       wp.M = N;
       wjob(wp, w.dPs, x_in, g + me.W[0], 3 * L, 0, nullptr);       // dW0s
       wjob(wp, w.dPd, x_in, g + me.W[0], 3 * L, L, g + me.B[0]);   // dW0d, db0
       HIP_TRY(launch_wgrad_batch(L, wp, w.gpart, w.cpart, s), "projection weight gradients");
-      HIP_TRY(launch_rows_gemm_add(L, w.dX, w.dPs, mat(20), w.dPd, mat(21), N, s), "dx from the projections");
+      HIP_TRY(launch_rows_gemm_add(L, split, w.dX, w.dPs, mat(20), w.dPd, mat(21), N, s), "dx from the projections");
     }
   }
   // ---- input embeddings (src/mpn/input_embedding.py:41-42; Embedding.forward, src/mpn/common/embedding.py:44-54) ----
@@ -912,12 +933,13 @@ int backward_impl(const AmberMpnDesc* desc, const float* params, const float* pa
       a0 = a0buf;
       PackBatch pb{};
       for (int l = 1; l < K; ++l) {
-        pb.job[pb.n++] = PackJob{params + m.W[l], mat(2 * (l - 1)), L, 0, 0};
-        pb.job[pb.n++] = PackJob{params + m.W[l], mat(2 * (l - 1) + 1), L, 0, 1};
+        pb.job[pb.n++] = PackJob{params + m.W[l], mat(2 * (l - 1)), L, 0, 0, fmt};
+        pb.job[pb.n++] = PackJob{params + m.W[l], mat(2 * (l - 1) + 1), L, 0, 1, fmt};
       }
       HIP_TRY(launch_pack_batch(L, pb, s), "pack embedding matrices");
       ChainBwdArgs a{};
       a.mode = AMBER_BWD_NODE;
+      a.split = split;
       a.rows = rows;
       a.rin = a0;
       a.m = nullptr;  // no aggregate: a plain dense chain
@@ -940,6 +962,7 @@ int backward_impl(const AmberMpnDesc* desc, const float* params, const float* pa
       a.dio = dio;
       HIP_TRY(launch_chain_bwd(L, a, s), "embedding MLP backward kernel");
       WgradBatch wb{};
+      wb.split = split;
       wb.M = rows;
       wjob(wb, DH[0], a0, g + m.W[1], L, 0, g + m.B[1]);
       for (int l = 1; l < K - 1; ++l) wjob(wb, DH[l], A[l - 1], g + m.W[l + 1], L, 0, g + m.B[l + 1]);
@@ -1008,7 +1031,7 @@ int amber_mpn_pack_weights(const AmberMpnDesc* desc, const float* params, float*
       q2.job[q2.n++] = F2PackJob{W, out, ld, col0, scol0, scols, kperm};
       if (q2.n == kF2PackMaxJobs) return flush();
     } else {
-      q32.job[q32.n++] = PackJob{W, out, ld, col0, 0};
+      q32.job[q32.n++] = PackJob{W, out, ld, col0, 0, AMBER_PACK_F32};
       if (q32.n == kPackMaxJobs) return flush();
     }
     return hipSuccess;

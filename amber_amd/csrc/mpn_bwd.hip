@@ -47,6 +47,80 @@ DEVINL void tile_gemm_lean(Tile<L>& acc, const float* __restrict__ wpacked, cons
 #endif
   }
 }
+// ---- split operands for the fp16-rate matrix pipe: a float as THREE bf16 pieces (bf16x3) ----
+// x = p0 + p1 + p2 exactly: p0 = x truncated to its upper 16 bits, p1 = (x - p0) truncated, p2 = the rest (at most 8
+// significant bits are left, so it is a bf16 number).  bf16 keeps fp32's exponent, so - unlike the forward's fp16 hi/lo
+// pairs - no scale has to be carried, whatever the magnitude of a gradient row.  A product takes the six piece products
+// whose weight is 2^-16 or more (p1 p2, p2 p1, p2 p2 <= 2^-24 are dropped): 6 v_mfma_f32_32x32x16_bf16 of 8 passes for
+// 16 k-values against 8 v_mfma_f32_32x32x2_f32 of 16 passes - 2.7 times fewer matrix-pipe cycles, fp32-grade results
+// (relative error of a product <= 2^-22).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+DEVINL unsigned pack_upper_halves(float first, float second) {  // (upper 16 bits of second) << 16 | upper 16 bits of first
+  return __builtin_amdgcn_perm(__float_as_uint(second), __float_as_uint(first), 0x07060302u);
+}
+DEVINL void split3(const float (&v)[8], u32x4 (&p)[3]) {
+  float r1[8], r2[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    r1[i] = v[i] - __uint_as_float(__float_as_uint(v[i]) & 0xffff0000u);
+    r2[i] = r1[i] - __uint_as_float(__float_as_uint(r1[i]) & 0xffff0000u);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    p[0][q] = pack_upper_halves(v[2 * q], v[2 * q + 1]);
+    p[1][q] = pack_upper_halves(r1[2 * q], r1[2 * q + 1]);
+    p[2][q] = pack_upper_halves(r2[2 * q], r2[2 * q + 1]);
+  }
+}
+DEVINL f32x16 mfma_b(const u32x4& a, const u32x4& b, const f32x16& c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// the six piece products of one 32 x 32 x 16 step, small terms first
+#define AMBER_B3_PRODUCTS(ACC, W, X) \
+  ACC = mfma_b(W[2], X[0], ACC);     \
+  ACC = mfma_b(W[0], X[2], ACC);     \
+  ACC = mfma_b(W[1], X[1], ACC);     \
+  ACC = mfma_b(W[1], X[0], ACC);     \
+  ACC = mfma_b(W[0], X[1], ACC);     \
+  ACC = mfma_b(W[0], X[0], ACC)
+
+// acc += W * in with W in bf16x3 operand order (pack_batch_kernel, fmt 1): k-step s takes this lane's registers
+// 8 (s & 1) .. + 7 of block s / 2, i.e. features 16 s + 8 (jj / 4) + 4 h + jj % 4 - the accumulator layout is the operand
+// layout, nothing moves between lanes.
+template <int L>
+DEVINL void tile_gemm_b3(Tile<L>& acc, const float* __restrict__ wpacked, const Tile<L>& in, int lane) {
+  constexpr int NFB = L / 32, NS = L / 16;
+  const u32x4* __restrict__ w = reinterpret_cast<const u32x4*>(wpacked) + lane;
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    u32x4 wf[NFB][3];
+#pragma unroll
+    for (int fb = 0; fb < NFB; ++fb)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) wf[fb][q] = w[((s * NFB + fb) * 3 + q) * 64];
+    float v[8];
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) v[jj] = in.a[s >> 1][8 * (s & 1) + jj];
+    u32x4 x[3];
+    split3(v, x);
+#pragma unroll
+    for (int fb = 0; fb < NFB; ++fb) {
+      AMBER_B3_PRODUCTS(acc.a[fb], wf[fb], x);
+    }
+#ifdef AMBER_BWD_SCHED_BARRIER
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+  }
+}
+template <int L, bool B3>
+DEVINL void tile_gemm_sel(Tile<L>& acc, const float* __restrict__ wpacked, const Tile<L>& in, int lane) {
+  if constexpr (B3)
+    tile_gemm_b3<L>(acc, wpacked, in, lane);
+  else
+    tile_gemm_lean<L>(acc, wpacked, in, lane);
+}
 template <int L>
 DEVINL void tile_store_w(float* stage, const Tile<L>& t, float* __restrict__ out, int64_t row0, int nvalid, int lane) {
   wave_sync();
@@ -169,7 +243,7 @@ DEVINL void wave_global_handover() {
 //     AP[l], the next layer reads n_l = LN_l(a_l); the (d gamma_l, d beta_l) column sums are added per wave into
 //     pn_part[wave][l][2][L] (every wave owns its slots: no atomics, fixed order).
 // ---------------------------------------------------------------------------------------------------
-template <int L, bool EXT>
+template <int L, bool EXT, bool B3>
 __global__ __launch_bounds__(kBlock, L <= 64 ? 2 : 1) void chain_bwd_kernel(const ChainBwdArgs a, const int64_t ntiles) {
   __shared__ __attribute__((aligned(16))) float stage_all[kWavesPerBlock * stage_floats<L>()];
   const int lane0 = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -220,13 +294,13 @@ __global__ __launch_bounds__(kBlock, L <= 64 ? 2 : 1) void chain_bwd_kernel(cons
           const int s = a.src[p];
           tile_load_row<L>(cur, a.Ps, s, h);
           tile_add_row<L>(cur, a.Pd, d, h);
-          tile_gemm_lean<L>(cur, a.w_in, rin, lane);
+          tile_gemm_sel<L, B3>(cur, a.w_in, rin, lane);
         } else {
           tile_load_vec<L>(cur, a.b0, h);
-          tile_gemm_lean<L>(cur, a.w_in, rin, lane);
+          tile_gemm_sel<L, B3>(cur, a.w_in, rin, lane);
           if (has_m) {
             tile_load_row<L>(rin, a.m, p, h);
-            tile_gemm_lean<L>(cur, a.w_m, rin, lane);
+            tile_gemm_sel<L, B3>(cur, a.w_m, rin, lane);
           }
         }
       }
@@ -244,7 +318,7 @@ __global__ __launch_bounds__(kBlock, L <= 64 ? 2 : 1) void chain_bwd_kernel(cons
         tile_store_w<L>(stage, cur, a.A[l - 1], p0, nvalid, lane);  // input of layer l: needed by dW_l and by act' below
         Tile<L> nxt;
         tile_load_vec<L>(nxt, a.layers[l].b, h);
-        tile_gemm_lean<L>(nxt, a.layers[l].w, cur, lane);
+        tile_gemm_sel<L, B3>(nxt, a.layers[l].w, cur, lane);
         tile_act_w<L>(nxt, a.act, stage, lane);
         cur = nxt;
         if constexpr (EXT) {
@@ -380,7 +454,7 @@ __global__ __launch_bounds__(kBlock, L <= 64 ? 2 : 1) void chain_bwd_kernel(cons
         tile_store_w<L>(stage, dr, a.DH[l], p0, nvalid, lane);
         Tile<L> nd;
         tile_zero<L>(nd);
-        tile_gemm_lean<L>(nd, a.wT[l], dr, lane);
+        tile_gemm_sel<L, B3>(nd, a.wT[l], dr, lane);
         dr = nd;
       }
       if (dnorm)
@@ -391,7 +465,7 @@ __global__ __launch_bounds__(kBlock, L <= 64 ? 2 : 1) void chain_bwd_kernel(cons
       tile_store_w<L>(stage, dr, a.DH[0], p0, nvalid, lane);
       if (has_m) {
         tile_zero<L>(cur);
-        tile_gemm_lean<L>(cur, a.wT_m, dr, lane);
+        tile_gemm_sel<L, B3>(cur, a.wT_m, dr, lane);
         tile_store_w<L>(stage, cur, a.dm_out, p0, nvalid, lane);
       }
       // gradient at the first layer's streamed input (+ the parked residual term; head: + what arrived at the latents)
@@ -399,7 +473,7 @@ __global__ __launch_bounds__(kBlock, L <= 64 ? 2 : 1) void chain_bwd_kernel(cons
         tile_load_row<L>(cur, a.dio, p, h);
       else
         tile_zero<L>(cur);
-      tile_gemm_lean<L>(cur, a.wT_in, dr, lane);
+      tile_gemm_sel<L, B3>(cur, a.wT_in, dr, lane);
       tile_store_w<L>(stage, cur, a.dio, p0, nvalid, lane);
     } else {
       if (a.mode == AMBER_BWD_HEAD) tile_add_row<L>(dr, a.dio, p, h);
@@ -471,7 +545,7 @@ struct WgradCfg {
 };
 
 // blockIdx.y selects the job of a batch (products over the same rows M: the weight matrices of one module)
-template <int L>
+template <int L, bool B3>
 __global__ __launch_bounds__(512) void wgrad_kernel(const WgradBatch jobs, int64_t chunk, float* __restrict__ part_all,
                                                     float* __restrict__ cpart_all) {
   const WgradJob jb = jobs.job[blockIdx.y];
@@ -503,6 +577,52 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const WgradBatch jobs, int64
   float cs[TA];
 #pragma unroll
   for (int ta = 0; ta < TA; ++ta) cs[ta] = 0.f;
+  if constexpr (B3) {
+    // bf16x3 (see split3): 16 rows per instruction; lane (h, c) holds rows r + 8 h .. + 7 of its features
+    for (int64_t r = rs0; r < rs1; r += 16) {
+      veca av[8];
+      vecf bv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int64_t rr = r + 8 * h + u;
+        const bool ok = rr < rs1;
+        const int64_t rc = ok ? rr : rs0;
+        veca x = *reinterpret_cast<const veca*>(A + rc * L + VEC * c + TA * grp);
+        vecf y = *reinterpret_cast<const vecf*>(B + rc * L + VEC * c);
+        if (!ok) {
+          x = x * 0.f;
+          y = y * 0.f;
+        }
+        av[u] = x;
+        bv[u] = y;
+      }
+      u32x4 ap[TA][3];
+#pragma unroll
+      for (int ta = 0; ta < TA; ++ta) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if constexpr (TA == 1) v[u] = av[u]; else v[u] = av[u][ta];
+          cs[ta] += v[u];
+        }
+        split3(v, ap[ta]);
+      }
+#pragma unroll
+      for (int tb = 0; tb < VEC; ++tb) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if constexpr (VEC == 1) v[u] = bv[u]; else v[u] = bv[u][tb];
+        }
+        u32x4 bp[3];
+        split3(v, bp);
+#pragma unroll
+        for (int ta = 0; ta < TA; ++ta) {
+          AMBER_B3_PRODUCTS(acc[ta][tb], ap[ta], bp);
+        }
+      }
+    }
+  } else
   for (int64_t r = rs0; r < rs1; r += 2 * U) {
     veca av[U];
     vecf bv[U];
@@ -710,7 +830,7 @@ __global__ void segment_reduce_kernel(const float* __restrict__ vals, const int3
 }
 
 // io[r] += W0 in0[r] + W1 in1[r] on row tiles (W packed): dx += W0s^T dP_s + W0d^T dP_d
-template <int L>
+template <int L, bool B3>
 __global__ __launch_bounds__(kBlock) void rows_gemm_add_kernel(float* __restrict__ io, const float* __restrict__ in0,
                                                                const float* __restrict__ w0, const float* __restrict__ in1,
                                                                const float* __restrict__ w1, int64_t rows, int64_t ntiles) {
@@ -727,10 +847,10 @@ __global__ __launch_bounds__(kBlock) void rows_gemm_add_kernel(float* __restrict
   Tile<L> acc, t;
   tile_load_row<L>(acc, io, p, h);
   tile_load_row<L>(t, in0, p, h);
-  tile_gemm<L>(acc, w0, t, lane);
+  tile_gemm_sel<L, B3>(acc, w0, t, lane);
   if (in1) {
     tile_load_row<L>(t, in1, p, h);
-    tile_gemm<L>(acc, w1, t, lane);
+    tile_gemm_sel<L, B3>(acc, w1, t, lane);
   }
   tile_store_w<L>(stage, acc, io, p0, nvalid, lane);
 }
@@ -757,6 +877,26 @@ __global__ void pack_batch_kernel(const PackBatch jobs) {
   constexpr int NFB = L / 32;
   const PackJob jb = jobs.job[blockIdx.y];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;  // float4 index
+  if (jb.fmt == AMBER_PACK_B3) {
+    // bf16x3 operand order (tile_gemm_b3): one thread per (k-step s, output block fb, lane); the lane's eight k-values of
+    // the step as three 16-byte piece vectors, 64 lanes of a piece contiguous
+    if (i >= (L / 16) * NFB * 64) return;
+    const int lane = i & 63, fb = (i >> 6) % NFB, s = (i >> 6) / NFB;
+    const int r = 32 * fb + (lane & 31), h = lane >> 5;
+    float v[8];
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+      const int k = 16 * s + 8 * (jj >> 2) + 4 * h + (jj & 3);
+      v[jj] = jb.transpose ? jb.W[static_cast<int64_t>(k) * jb.ld + jb.col0 + r] : jb.W[static_cast<int64_t>(r) * jb.ld + jb.col0 + k];
+    }
+    u32x4 pc[3];
+    split3(v, pc);
+    u32x4* out = reinterpret_cast<u32x4*>(jb.out) + static_cast<int64_t>((s * NFB + fb) * 3) * 64 + lane;
+    out[0] = pc[0];
+    out[64] = pc[1];
+    out[128] = pc[2];
+    return;
+  }
   if (i >= L * L / 4) return;
   const int lane = i & 63, fb = (i >> 6) % NFB, j = (i >> 6) / NFB;
   const int r = 32 * fb + (lane & 31), k0 = 8 * j + 4 * (lane >> 5);
@@ -788,10 +928,21 @@ static hipError_t launch_chain_bwd_t(const ChainBwdArgs& a, hipStream_t s) {
   const int64_t ntiles = cdiv(a.rows, kTile);
   const bool ext = a.residual == AMBER_MODE_OUTER || a.layer_norm == AMBER_MODE_OUTER ||
                    (a.mode == AMBER_BWD_NODE && a.m == nullptr) || (a.mode == AMBER_BWD_HEAD && a.pn_gamma[0] != nullptr);
+  const dim3 grid(chain_bwd_grid(a.rows));
+  if constexpr (L <= 128) {
+    if (a.split) {
+      if (ext)
+        hipLaunchKernelGGL((chain_bwd_kernel<L, true, true>), grid, dim3(kBlock), 0, s, a, ntiles);
+      else
+        hipLaunchKernelGGL((chain_bwd_kernel<L, false, true>), grid, dim3(kBlock), 0, s, a, ntiles);
+      return hipGetLastError();
+    }
+  }
+  if (a.split) return hipErrorInvalidValue;  // bwd_split_supported(L) is the caller's check
   if (ext)
-    hipLaunchKernelGGL((chain_bwd_kernel<L, true>), dim3(chain_bwd_grid(a.rows)), dim3(kBlock), 0, s, a, ntiles);
+    hipLaunchKernelGGL((chain_bwd_kernel<L, true, false>), grid, dim3(kBlock), 0, s, a, ntiles);
   else
-    hipLaunchKernelGGL((chain_bwd_kernel<L, false>), dim3(chain_bwd_grid(a.rows)), dim3(kBlock), 0, s, a, ntiles);
+    hipLaunchKernelGGL((chain_bwd_kernel<L, false, false>), grid, dim3(kBlock), 0, s, a, ntiles);
   return hipGetLastError();
 }
 hipError_t launch_chain_bwd(int L, const ChainBwdArgs& a, hipStream_t s) {
@@ -873,15 +1024,15 @@ int wgrad_chunks(int64_t M, int njobs, int64_t* chunk_out) {
   if (chunk_out) *chunk_out = chunk;
   return static_cast<int>(G);
 }
-template <int L>
+template <int L, bool B3>
 static hipError_t launch_wgrad_t(const WgradBatch& b, float* part, float* cpart, hipStream_t s) {
   int64_t chunk = 0;
   const int G = wgrad_chunks(b.M, b.n, &chunk);
   const size_t lds = WgradCfg<L>::lds_bytes();
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<L>), hipFuncAttributeMaxDynamicSharedMemorySize,
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<L, B3>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      static_cast<int>(lds));
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(wgrad_kernel<L>, dim3(G, b.n), dim3(512), lds, s, b, chunk, part, cpart);
+  hipLaunchKernelGGL((wgrad_kernel<L, B3>), dim3(G, b.n), dim3(512), lds, s, b, chunk, part, cpart);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(L * L + L, 64), b.n), dim3(256), 0, s, b, part, cpart, G, L);
@@ -890,19 +1041,21 @@ static hipError_t launch_wgrad_t(const WgradBatch& b, float* part, float* cpart,
 hipError_t launch_wgrad_batch(int L, const WgradBatch& b, float* part, float* cpart, hipStream_t s) {
   if (b.M == 0 || b.n == 0) return hipSuccess;
   if (b.n > kWgradMaxJobs) return hipErrorInvalidValue;
+  if (b.split && !bwd_split_supported(L)) return hipErrorInvalidValue;
   switch (L) {
-    case 32: return launch_wgrad_t<32>(b, part, cpart, s);
-    case 64: return launch_wgrad_t<64>(b, part, cpart, s);
-    case 128: return launch_wgrad_t<128>(b, part, cpart, s);
-    case 256: return launch_wgrad_t<256>(b, part, cpart, s);
+    case 32: return b.split ? launch_wgrad_t<32, true>(b, part, cpart, s) : launch_wgrad_t<32, false>(b, part, cpart, s);
+    case 64: return b.split ? launch_wgrad_t<64, true>(b, part, cpart, s) : launch_wgrad_t<64, false>(b, part, cpart, s);
+    case 128: return b.split ? launch_wgrad_t<128, true>(b, part, cpart, s) : launch_wgrad_t<128, false>(b, part, cpart, s);
+    case 256: return launch_wgrad_t<256, false>(b, part, cpart, s);
     default: return hipErrorInvalidValue;
   }
 }
-hipError_t launch_wgrad(int L, const float* A, const float* B, int64_t M, float* dW, int ld, int col0, float* db, float* part,
-                        float* cpart, hipStream_t s) {
+hipError_t launch_wgrad(int L, int split, const float* A, const float* B, int64_t M, float* dW, int ld, int col0, float* db,
+                        float* part, float* cpart, hipStream_t s) {
   WgradBatch b{};
   b.n = 1;
   b.M = M;
+  b.split = split;
   b.job[0] = WgradJob{A, B, dW, db, ld, col0};
   return launch_wgrad_batch(L, b, part, cpart, s);
 }
@@ -946,22 +1099,23 @@ hipError_t launch_segment_reduce(const float* vals, const int32_t* rowptr, const
   return hipGetLastError();
 }
 
-template <int L>
+template <int L, bool B3>
 static hipError_t launch_rows_gemm_add_t(float* io, const float* in0, const float* w0, const float* in1, const float* w1, int64_t rows,
                                          hipStream_t s) {
   const int64_t ntiles = cdiv(rows, kTile);
-  hipLaunchKernelGGL(rows_gemm_add_kernel<L>, dim3(static_cast<unsigned>(cdiv(ntiles, kWavesPerBlock))), dim3(kBlock), 0, s, io, in0, w0,
-                     in1, w1, rows, ntiles);
+  hipLaunchKernelGGL((rows_gemm_add_kernel<L, B3>), dim3(static_cast<unsigned>(cdiv(ntiles, kWavesPerBlock))), dim3(kBlock), 0, s, io,
+                     in0, w0, in1, w1, rows, ntiles);
   return hipGetLastError();
 }
-hipError_t launch_rows_gemm_add(int L, float* io, const float* in0, const float* w0, const float* in1, const float* w1, int64_t rows,
-                                hipStream_t s) {
+hipError_t launch_rows_gemm_add(int L, int split, float* io, const float* in0, const float* w0, const float* in1, const float* w1,
+                                int64_t rows, hipStream_t s) {
   if (rows == 0) return hipSuccess;
+  if (split && !bwd_split_supported(L)) return hipErrorInvalidValue;
   switch (L) {
-    case 32: return launch_rows_gemm_add_t<32>(io, in0, w0, in1, w1, rows, s);
-    case 64: return launch_rows_gemm_add_t<64>(io, in0, w0, in1, w1, rows, s);
-    case 128: return launch_rows_gemm_add_t<128>(io, in0, w0, in1, w1, rows, s);
-    case 256: return launch_rows_gemm_add_t<256>(io, in0, w0, in1, w1, rows, s);
+    case 32: return split ? launch_rows_gemm_add_t<32, true>(io, in0, w0, in1, w1, rows, s) : launch_rows_gemm_add_t<32, false>(io, in0, w0, in1, w1, rows, s);
+    case 64: return split ? launch_rows_gemm_add_t<64, true>(io, in0, w0, in1, w1, rows, s) : launch_rows_gemm_add_t<64, false>(io, in0, w0, in1, w1, rows, s);
+    case 128: return split ? launch_rows_gemm_add_t<128, true>(io, in0, w0, in1, w1, rows, s) : launch_rows_gemm_add_t<128, false>(io, in0, w0, in1, w1, rows, s);
+    case 256: return launch_rows_gemm_add_t<256, false>(io, in0, w0, in1, w1, rows, s);
     default: return hipErrorInvalidValue;
   }
 }

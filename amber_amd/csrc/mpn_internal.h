@@ -172,8 +172,15 @@ constexpr int kBwdWavesPerBlock = 4;   // = kWavesPerBlock of mpn_tile.h (checke
 constexpr int kWgradMaxChunks = 512;   // split-K chunks of a weight-gradient product
 // Recompute + chain rule of one module on 32-row tiles (see chain_bwd_kernel).  All matrices in the exact fp32 operand
 // order (launch_pack / launch_pack_t).
+// Operand format of the backward's contractions: exact fp32 (v_mfma_f32_32x32x2_f32) or every float as three bf16 pieces
+// on the fp16-rate pipe (bf16x3, see split3 in mpn_bwd.hip: fp32-grade, 2.7 times fewer matrix-pipe cycles).
+constexpr int AMBER_PACK_F32 = 0, AMBER_PACK_B3 = 1;
+constexpr bool bwd_split_supported(int L) { return L == 32 || L == 64 || L == 128; }
+// floats of one packed matrix of the backward in either format (bf16x3: three 2-byte pieces a value)
+constexpr size_t bwd_mat_floats(int L) { return static_cast<size_t>(L) * L * 3 / 2 + kPackedHeader; }
 struct ChainBwdArgs {
   int32_t mode;           // AMBER_BWD_*
+  int32_t split;          // 0: matrices packed AMBER_PACK_F32; 1: AMBER_PACK_B3
   int64_t rows;           // E (edge) or N (node, head)
   const float* rin;       // [rows,L] streamed input of the first layer and residual term: e_in / x_in
   const float* Ps;        // edge: [N,L] source part of the first layer
@@ -232,18 +239,20 @@ struct WgradJob {
 struct WgradBatch {
   WgradJob job[kWgradMaxJobs];
   int32_t n;
+  int32_t split;  // 1: bf16x3 operands
   int64_t M;
 };
 int wgrad_chunks(int64_t M, int njobs, int64_t* chunk_out);
 hipError_t launch_wgrad_batch(int L, const WgradBatch& b, float* part, float* cpart, hipStream_t s);
 // dW[:, col0:col0+L] += A^T B (A, B: [M,L]); db += column sums of A (db may be nullptr)
-hipError_t launch_wgrad(int L, const float* A, const float* B, int64_t M, float* dW, int ld, int col0, float* db, float* part,
-                        float* cpart, hipStream_t s);
+hipError_t launch_wgrad(int L, int split, const float* A, const float* B, int64_t M, float* dW, int ld, int col0, float* db,
+                        float* part, float* cpart, hipStream_t s);
 constexpr int kPackMaxJobs = 16;
 struct PackJob {
   const float* W;
   float* out;
   int32_t ld, col0, transpose;
+  int32_t fmt;  // AMBER_PACK_F32 / AMBER_PACK_B3
 };
 struct PackBatch {
   PackJob job[kPackMaxJobs];
@@ -255,8 +264,8 @@ hipError_t launch_embed_bwd(int L, const float* d, const float* raw, const int32
                             float* part, hipStream_t s);
 hipError_t launch_segment_reduce(const float* vals, const int32_t* rowptr, const int32_t* idx, int64_t N, int L, int mean, float* out,
                                  hipStream_t s);
-hipError_t launch_rows_gemm_add(int L, float* io, const float* in0, const float* w0, const float* in1, const float* w1, int64_t rows,
-                                hipStream_t s);
+hipError_t launch_rows_gemm_add(int L, int split, float* io, const float* in0, const float* w0, const float* in1, const float* w1,
+                                int64_t rows, hipStream_t s);
 hipError_t launch_pack_t(int L, const float* W, int ld, int col0, float* out, hipStream_t s);
 
 // ---- pre / post glue of _predict, glue.hip ----
