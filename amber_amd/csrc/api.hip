@@ -280,11 +280,12 @@ struct Timer {
 // Debug switches of the environment, read ONCE per process: the packed-buffer layout depends on them (use_fast_head), so
 // a value that changed between amber_mpn_pack_weights and a forward would make the kernels read the wrong matrices.
 struct EnvSwitches {
-  bool no_fused_head, no_fused_embed, exact_backward;
+  bool no_fused_head, no_fused_embed, exact_backward, no_fused_backward;
   EnvSwitches()
       : no_fused_head(getenv("AMBER_MPN_NO_FUSED_HEAD") != nullptr),
         no_fused_embed(getenv("AMBER_MPN_NO_FUSED_EMBED") != nullptr),
-        exact_backward(getenv("AMBER_MPN_EXACT_BACKWARD") != nullptr) {}
+        exact_backward(getenv("AMBER_MPN_EXACT_BACKWARD") != nullptr),
+        no_fused_backward(getenv("AMBER_MPN_NO_FUSED_BACKWARD") != nullptr) {}
 };
 const EnvSwitches& env_switches() {
   static const EnvSwitches e;
@@ -895,14 +896,22 @@ int backward_impl(const AmberMpnDesc* desc, const float* params, const float* pa
       a.dio = w.dE;
       a.dm_in = w.DM;
       a.part = ln ? w.lnpart : nullptr;
-      HIP_TRY(launch_chain_bwd(L, a, s), "edge backward kernel");
-      if (ln) HIP_TRY(launch_colpart_reduce(w.lnpart, ge, L, g + lay.eg[step], L, g + lay.eb[step], L, s), "edge LayerNorm gradient");
       WgradBatch we{};
       we.split = split;
       we.M = E;
       wjob(we, w.DHE[0], e_in, g + me.W[0], 3 * L, 2 * L, nullptr);  // dW0e
       for (int l = 1; l < nl; ++l) wjob(we, w.DHE[l], w.AE[l - 1], g + me.W[l], L, 0, g + me.B[l]);
-      HIP_TRY(launch_wgrad_batch(L, we, w.gpart, w.cpart, s), "edge weight gradients");
+      if (edge_bwd_fused_supported(L, a) && !env_switches().no_fused_backward) {
+        // chain and weight gradients in one pass over the edges; what is left of the latter is the ordered reduction
+        const int gf = edge_bwd_fused_grid(E);
+        HIP_TRY(launch_edge_bwd_fused(L, a, w.gpart, w.cpart, s), "fused edge backward kernel");
+        if (ln) HIP_TRY(launch_colpart_reduce(w.lnpart, gf, L, g + lay.eg[step], L, g + lay.eb[step], L, s), "edge LayerNorm gradient");
+        HIP_TRY(launch_wgrad_reduce(L, we, w.gpart, w.cpart, gf, s), "edge weight gradients (reduction)");
+      } else {
+        HIP_TRY(launch_chain_bwd(L, a, s), "edge backward kernel");
+        if (ln) HIP_TRY(launch_colpart_reduce(w.lnpart, ge, L, g + lay.eg[step], L, g + lay.eb[step], L, s), "edge LayerNorm gradient");
+        HIP_TRY(launch_wgrad_batch(L, we, w.gpart, w.cpart, s), "edge weight gradients");
+      }
       // gathered first-layer terms: gradients summed per destination (CSR rows) and per source (source-sorted order)
       HIP_TRY(launch_segment_reduce(w.DHE[0], rowptr, nullptr, N, L, 0, w.dPd, s), "dP_d");
       HIP_TRY(launch_segment_reduce(w.DHE[0], rowptr_src, perm_src, N, L, 0, w.dPs, s), "dP_s");

@@ -77,7 +77,9 @@ DEVINL void split3(const float (&v)[8], u32x4 (&p)[3]) {
 DEVINL f32x16 mfma_b(const u32x4& a, const u32x4& b, const f32x16& c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
-// the six piece products of one 32 x 32 x 16 step, small terms first
+// the six piece products of one 32 x 32 x 16 step, small terms first: (piece of the first operand, piece of the second)
+__device__ constexpr int kB3W[6] = {2, 0, 1, 1, 0, 0};
+__device__ constexpr int kB3X[6] = {0, 2, 1, 0, 1, 0};
 #define AMBER_B3_PRODUCTS(ACC, W, X) \
   ACC = mfma_b(W[2], X[0], ACC);     \
   ACC = mfma_b(W[0], X[2], ACC);     \
@@ -105,10 +107,11 @@ DEVINL void tile_gemm_b3(Tile<L>& acc, const float* __restrict__ wpacked, const 
     for (int jj = 0; jj < 8; ++jj) v[jj] = in.a[s >> 1][8 * (s & 1) + jj];
     u32x4 x[3];
     split3(v, x);
+    // piece product outer, output block inner: consecutive instructions are independent chains
 #pragma unroll
-    for (int fb = 0; fb < NFB; ++fb) {
-      AMBER_B3_PRODUCTS(acc.a[fb], wf[fb], x);
-    }
+    for (int q = 0; q < 6; ++q)
+#pragma unroll
+      for (int fb = 0; fb < NFB; ++fb) acc.a[fb] = mfma_b(wf[fb][kB3W[q]], x[kB3X[q]], acc.a[fb]);
 #ifdef AMBER_BWD_SCHED_BARRIER
     __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -498,6 +501,211 @@ __global__ __launch_bounds__(kBlock, L <= 64 ? 2 : 1) void chain_bwd_kernel(cons
       for (int w = 1; w < kWavesPerBlock; ++w) sum += red[w * 2 * L + i];
       a.part[static_cast<int64_t>(blockIdx.x) * 2 * L + i] = sum;
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// fused edge backward (latent <= 64, two layers, inner / no residual and LayerNorm, bf16x3 operands): the chain of
+// chain_bwd_kernel in mode EDGE AND the module's weight gradients in one pass over the edges.  The chain kernel's
+// intermediates (A_0, DH_1, the parked residual term, and DH_0 / e read again by the weight-gradient kernel) are 11 of
+// the 15 edge-sized tensors one step's backward moves through HBM; here A_0, the residual term and the input rows stay
+// in registers and every wave keeps its own dW_0e = DH_0^T e and dW_1 = DH_1^T A_0 in 2 (L/32)^2 accumulator tiles - one
+// wave per SIMD (512 registers a lane).  The rows are the contraction dimension of those products: both tiles go through
+// the wave's two LDS stages and come back transposed (lane (h, m): rows 16 s + 8 h .. + 7 of feature column m), as
+// bf16x3 pieces.  What still leaves the kernel per edge: DH_0 (the per-source and per-destination sums need it) and the
+// gradient at e.  Per-workgroup partial products go to wgrad_reduce_kernel like the split-K partials of wgrad_kernel.
+// ---------------------------------------------------------------------------------------------------
+template <int L>
+DEVINL void tile_wgrad_b3(f32x16 (&acc)[L / 32][L / 32], const float* sx, const float* sy, int c, int h) {
+  constexpr int NFB = L / 32, ST = stage_stride<L>();
+#pragma unroll
+  for (int s = 0; s < kTile / 16; ++s) {
+    u32x4 xp[NFB][3], yp[NFB][3];
+    const int r0 = 16 * s + 8 * h;
+#pragma unroll
+    for (int fb = 0; fb < NFB; ++fb) {
+      float v[8];
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) v[jj] = sx[(r0 + jj) * ST + 32 * fb + c];
+      split3(v, xp[fb]);
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) v[jj] = sy[(r0 + jj) * ST + 32 * fb + c];
+      split3(v, yp[fb]);
+    }
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+#pragma unroll
+      for (int fo = 0; fo < NFB; ++fo)
+#pragma unroll
+        for (int fi = 0; fi < NFB; ++fi) acc[fo][fi] = mfma_b(xp[fo][kB3W[q]], yp[fi][kB3X[q]], acc[fo][fi]);
+  }
+}
+
+template <int L>
+__global__ __launch_bounds__(kBlock, 1) void edge_bwd_fused_kernel(const ChainBwdArgs a, const int64_t ntiles, float* __restrict__ wpart,
+                                                                    float* __restrict__ cpart) {
+  extern __shared__ __attribute__((aligned(16))) float lds_fused[];
+  constexpr int NFB = L / 32, SF = stage_floats<L>(), ST = stage_stride<L>();
+  const int lane0 = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float* sx = lds_fused + (2 * wave) * SF;
+  float* sy = sx + SF;
+  constexpr int FPL = (L + 63) / 64;
+  const bool active = lane0 * FPL < L;
+  const int fo = active ? lane0 * FPL : 0;
+  float ps0[FPL], ps1[FPL], ps2[FPL];
+#pragma unroll
+  for (int q = 0; q < FPL; ++q) ps0[q] = ps1[q] = ps2[q] = 0.f;
+  f32x16 g0[NFB][NFB], g1[NFB][NFB];
+#pragma unroll
+  for (int i = 0; i < NFB; ++i)
+#pragma unroll
+    for (int j = 0; j < NFB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) g0[i][j][r] = g1[i][j][r] = 0.f;
+  const bool ln = a.layer_norm == AMBER_MODE_INNER, res = a.residual == AMBER_MODE_INNER;
+
+  const int64_t gw = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave;
+  const int64_t G = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
+  for (int64_t tile = gw; tile < ntiles; tile += G) {
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));  // see chain_bwd_kernel: keeps the weight tiles from being hoisted out of the loop
+    const int c = lane & 31, h = lane >> 5;
+    const int64_t p0 = tile * kTile;
+    const int nvalid = (a.rows - p0) < kTile ? static_cast<int>(a.rows - p0) : kTile;
+    int64_t p = p0 + c;
+    if (p > a.rows - 1) p = a.rows - 1;
+    const bool rowok = c < nvalid;
+    const int d = a.dst[p], sidx = a.src[p];
+    // ---- recompute: a0 = act(P_s[src] + P_d[dst] + W0e e), a1 = act(W1 a0 + b1) ----
+    Tile<L> rin, a0, a1, dr, keep;
+    tile_load_row<L>(rin, a.rin, p, h);
+    tile_load_row<L>(a0, a.Ps, sidx, h);
+    tile_add_row<L>(a0, a.Pd, d, h);
+    tile_load_row<L>(dr, a.dio, p, h);  // the incoming gradient, asked for early
+    const int deg = a.rowptr[d + 1] - a.rowptr[d];
+    tile_gemm_b3<L>(a0, a.w_in, rin, lane);
+    tile_act_w<L>(a0, a.act, sx, lane);
+    tile_load_vec<L>(a1, a.layers[1].b, h);
+    tile_gemm_b3<L>(a1, a.layers[1].w, a0, lane);
+    tile_act_w<L>(a1, a.act, sx, lane);
+    // ---- gradient at the module's output: dE + DM[dst] / deg(dst) ----
+    {
+      const float inv = 1.0f / static_cast<float>(max(deg, 1));
+      const f32x4* pm = reinterpret_cast<const f32x4*>(a.dm_in + static_cast<int64_t>(d) * L) + h;
+#pragma unroll
+      for (int j = 0; j < L / 8; ++j) tile_set_chunk<L>(dr, j, tile_get_chunk<L>(dr, j) + inv * pm[2 * j]);
+    }
+    if (!rowok) tile_zero<L>(dr);
+    // ---- LayerNorm backward (as in chain_bwd_kernel) ----
+    if (ln) {
+      Tile<L> xh = a1;
+      if (res) tile_add<L>(xh, rin);
+      const float rstd = tile_ln_xhat<L>(xh, a.eps);
+      tile_colsum_acc<L, FPL>(sx, dr, ps1, active, fo, lane);  // d beta
+      const f32x4* gp = reinterpret_cast<const f32x4*>(a.gamma) + h;
+      wave_sync();
+      {
+        f32x4* sp = reinterpret_cast<f32x4*>(sx + c * ST) + h;
+#pragma unroll
+        for (int j = 0; j < L / 8; ++j) sp[2 * j] = tile_get_chunk<L>(dr, j) * tile_get_chunk<L>(xh, j);
+      }
+      wave_sync();
+      if (active) {
+        for (int r = 0; r < kTile; ++r)
+#pragma unroll
+          for (int q = 0; q < FPL; ++q) ps0[q] += sx[r * ST + fo + q];  // d gamma
+      }
+#pragma unroll
+      for (int j = 0; j < L / 8; ++j) tile_set_chunk<L>(dr, j, tile_get_chunk<L>(dr, j) * gp[2 * j]);
+      const float m1 = tile_row_sum<L>(dr) * (1.0f / L);
+      const float m2 = tile_row_dot<L>(dr, xh) * (1.0f / L);
+#pragma unroll
+      for (int fb = 0; fb < NFB; ++fb) dr.a[fb] = (dr.a[fb] - m1 - xh.a[fb] * m2) * rstd;
+    }
+    keep = dr;  // the residual term of the input gradient
+    // ---- layer 1: DH1 = dr * act'(a1);  dW1 += DH1^T a0, db1 += column sums;  dr = W1^T DH1 ----
+    tile_mul_dact<L>(dr, a1, a.act);
+    wave_sync();
+    tile_stage<L>(sx, dr, c, h);
+    tile_stage<L>(sy, a0, c, h);
+    wave_sync();
+    if (active) {
+      for (int r = 0; r < kTile; ++r)
+#pragma unroll
+        for (int q = 0; q < FPL; ++q) ps2[q] += sx[r * ST + fo + q];
+    }
+    tile_wgrad_b3<L>(g1, sx, sy, c, h);
+    Tile<L> nd;
+    tile_zero<L>(nd);
+    tile_gemm_b3<L>(nd, a.wT[1], dr, lane);
+    // ---- layer 0: DH0 = nd * act'(a0);  dW0e += DH0^T e;  gradient at e = W0e^T DH0 (+ the residual term) ----
+    tile_mul_dact<L>(nd, a0, a.act);
+    wave_sync();
+    tile_stage<L>(sx, nd, c, h);
+    tile_stage<L>(sy, rin, c, h);
+    wave_sync();
+    stage_store_rows<L>(sx, a.DH[0], p0, nvalid, nullptr, lane);
+    tile_wgrad_b3<L>(g0, sx, sy, c, h);
+    if (!res) tile_zero<L>(keep);
+    tile_gemm_b3<L>(keep, a.wT_in, nd, lane);
+    tile_store_w<L>(sx, keep, a.dio, p0, nvalid, lane);
+  }
+  // ---- per-workgroup partials: column sums first, then the two products, waves added in wave order through LDS ----
+  __syncthreads();
+  {
+    float* red = lds_fused;  // [wave][3][L]
+    if (active) {
+#pragma unroll
+      for (int q = 0; q < FPL; ++q) {
+        red[(wave * 3 + 0) * L + fo + q] = ps0[q];
+        red[(wave * 3 + 1) * L + fo + q] = ps1[q];
+        red[(wave * 3 + 2) * L + fo + q] = ps2[q];
+      }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 3 * L; i += kBlock) {
+      float sum = red[i];
+#pragma unroll
+      for (int w = 1; w < kWavesPerBlock; ++w) sum += red[w * 3 * L + i];
+      if (i < 2 * L) {
+        if (a.part) a.part[static_cast<int64_t>(blockIdx.x) * 2 * L + i] = sum;
+      } else {
+        cpart[(static_cast<int64_t>(gridDim.x) + blockIdx.x) * L + (i - 2 * L)] = sum;  // job 1 (dW1)'s bias partial
+      }
+    }
+    __syncthreads();
+  }
+  constexpr int TF = NFB * NFB * 16 * 64;
+  const int lane = lane0, c = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int mtx = 0; mtx < 2; ++mtx) {
+    f32x16 (&g)[NFB][NFB] = mtx == 0 ? g0 : g1;
+    if (wave > 0) {
+      float* mine = lds_fused + static_cast<size_t>(wave - 1) * TF;
+#pragma unroll
+      for (int i = 0; i < NFB; ++i)
+#pragma unroll
+        for (int j = 0; j < NFB; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) mine[((i * NFB + j) * 16 + r) * 64 + lane] = g[i][j][r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+      float* P = wpart + (static_cast<int64_t>(mtx) * gridDim.x + blockIdx.x) * L * L;
+#pragma unroll
+      for (int i = 0; i < NFB; ++i)
+#pragma unroll
+        for (int j = 0; j < NFB; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float v = g[i][j][r];
+#pragma unroll
+            for (int w = 1; w < kWavesPerBlock; ++w) v += lds_fused[static_cast<size_t>(w - 1) * TF + ((i * NFB + j) * 16 + r) * 64 + lane];
+            const int m = (r & 3) + 8 * (r >> 2) + 4 * h;  // output feature within block i; input feature 32 j + c
+            P[(32 * i + m) * L + 32 * j + c] = v;
+          }
+    }
+    __syncthreads();
   }
 }
 
@@ -954,6 +1162,37 @@ hipError_t launch_chain_bwd(int L, const ChainBwdArgs& a, hipStream_t s) {
     case 256: return launch_chain_bwd_t<256>(a, s);
     default: return hipErrorInvalidValue;
   }
+}
+bool edge_bwd_fused_supported(int L, const ChainBwdArgs& a) {
+  return (L == 32 || L == 64) && a.split && a.mode == AMBER_BWD_EDGE && a.nl == 2 && a.residual != AMBER_MODE_OUTER &&
+         a.layer_norm != AMBER_MODE_OUTER;
+}
+int edge_bwd_fused_grid(int64_t rows) {
+  int64_t nblk = cdiv(cdiv(rows, kTile), kWavesPerBlock);
+  if (nblk > kFusedBwdBlocks) nblk = kFusedBwdBlocks;
+  if (nblk < 1) nblk = 1;
+  return static_cast<int>(nblk);
+}
+template <int L>
+static hipError_t launch_edge_bwd_fused_t(const ChainBwdArgs& a, float* wpart, float* cpart, hipStream_t s) {
+  const size_t lds = sizeof(float) * 2 * kWavesPerBlock * stage_floats<L>();
+  static_assert(sizeof(float) * 2 * kWavesPerBlock * stage_floats<L>() >= sizeof(float) * 3 * (L / 32) * (L / 32) * 16 * 64,
+                "the end-of-kernel reduction reuses the stages");
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(edge_bwd_fused_kernel<L>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     static_cast<int>(lds));
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(edge_bwd_fused_kernel<L>, dim3(edge_bwd_fused_grid(a.rows)), dim3(kBlock), lds, s, a, cdiv(a.rows, kTile), wpart, cpart);
+  return hipGetLastError();
+}
+hipError_t launch_edge_bwd_fused(int L, const ChainBwdArgs& a, float* wpart, float* cpart, hipStream_t s) {
+  if (a.rows == 0) return hipSuccess;
+  if (!edge_bwd_fused_supported(L, a)) return hipErrorInvalidValue;
+  return L == 32 ? launch_edge_bwd_fused_t<32>(a, wpart, cpart, s) : launch_edge_bwd_fused_t<64>(a, wpart, cpart, s);
+}
+hipError_t launch_wgrad_reduce(int L, const WgradBatch& b, const float* part, const float* cpart, int G, hipStream_t s) {
+  if (b.n == 0) return hipSuccess;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(L * L + L, 64), b.n), dim3(256), 0, s, b, part, cpart, G, L);
+  return hipGetLastError();
 }
 hipError_t launch_colpart_reduce(const float* part, int G, int L, float* out0, int n0, float* out1, int n1, hipStream_t s) {
   hipLaunchKernelGGL(colpart_reduce_kernel, dim3(2 * L), dim3(64), 0, s, part, G, static_cast<int64_t>(2 * L), L, out0, n0, out1, n1);

@@ -218,6 +218,12 @@ struct ChainBwdArgs {
   float* part;            // [grid waves][2][L] partial column sums: LayerNorm (d gamma, d beta) or readout (d wr, d br)
 };
 int chain_bwd_grid(int64_t rows);
+// chain + weight gradients of the edge module in one kernel (edge_bwd_fused_kernel): one workgroup per CU
+constexpr int kFusedBwdBlocks = 256;
+bool edge_bwd_fused_supported(int L, const ChainBwdArgs& a);
+int edge_bwd_fused_grid(int64_t rows);
+// wpart: [2][grid][L*L] partial products (dW0e, dW1), cpart: [2][grid][L] (slot 1: db1), a.part: [grid][2][L] LayerNorm sums
+hipError_t launch_edge_bwd_fused(int L, const ChainBwdArgs& a, float* wpart, float* cpart, hipStream_t s);
 hipError_t launch_chain_bwd(int L, const ChainBwdArgs& a, hipStream_t s);
 hipError_t launch_colpart_reduce(const float* part, int G, int L, float* out0, int n0, float* out1, int n1, hipStream_t s);
 // the same over partials that lie gstride floats apart (per-layer slots of pn_part)
@@ -243,6 +249,8 @@ struct WgradBatch {
   int64_t M;
 };
 int wgrad_chunks(int64_t M, int njobs, int64_t* chunk_out);
+// the ordered reduction of G partial products per job alone (partials laid out [job][G][L*L], [job][G][L])
+hipError_t launch_wgrad_reduce(int L, const WgradBatch& b, const float* part, const float* cpart, int G, hipStream_t s);
 hipError_t launch_wgrad_batch(int L, const WgradBatch& b, float* part, float* cpart, hipStream_t s);
 // dW[:, col0:col0+L] += A^T B (A, B: [M,L]); db += column sums of A (db may be nullptr)
 hipError_t launch_wgrad(int L, int split, const float* A, const float* B, int64_t M, float* dW, int ld, int col0, float* db,
