@@ -566,25 +566,42 @@ __global__ __launch_bounds__(kBlock, 1) void edge_bwd_fused_kernel(const ChainBw
 
   const int64_t gw = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave;
   const int64_t G = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
+  // a tile's endpoints and in-degree are fetched a tile ahead: vector-memory results return in order, so a tile's first
+  // loads wait for the previous tile's stores - with the indices already here, the row gathers go out at once
+  auto row_of = [&](int64_t t, int c_) {
+    const int64_t q = t * kTile + c_;
+    return q > a.rows - 1 ? a.rows - 1 : q;
+  };
+  int dn = 0, sn = 0, degn = 1;
+  if (gw < ntiles) {
+    const int64_t q = row_of(gw, lane0 & 31);
+    dn = a.dst[q];
+    sn = a.src[q];
+    degn = a.rowptr[dn + 1] - a.rowptr[dn];
+  }
   for (int64_t tile = gw; tile < ntiles; tile += G) {
     int lane = lane0;
     asm volatile("" : "+v"(lane));  // see chain_bwd_kernel: keeps the weight tiles from being hoisted out of the loop
     const int c = lane & 31, h = lane >> 5;
     const int64_t p0 = tile * kTile;
     const int nvalid = (a.rows - p0) < kTile ? static_cast<int>(a.rows - p0) : kTile;
-    int64_t p = p0 + c;
-    if (p > a.rows - 1) p = a.rows - 1;
+    const int64_t p = row_of(tile, c);
     const bool rowok = c < nvalid;
-    const int d = a.dst[p], sidx = a.src[p];
+    const int d = dn, sidx = sn, deg = degn;
     // ---- recompute: a0 = act(P_s[src] + P_d[dst] + W0e e), a1 = act(W1 a0 + b1) ----
     Tile<L> rin, a0, a1, dr, keep;
     tile_load_row<L>(rin, a.rin, p, h);
     tile_load_row<L>(a0, a.Ps, sidx, h);
     tile_add_row<L>(a0, a.Pd, d, h);
     tile_load_row<L>(dr, a.dio, p, h);  // the incoming gradient, asked for early
-    const int deg = a.rowptr[d + 1] - a.rowptr[d];
+    {
+      const int64_t q = row_of(tile + G < ntiles ? tile + G : tile, c);  // branch-free: the last tile asks for its own again
+      dn = a.dst[q];
+      sn = a.src[q];
+    }
     tile_gemm_b3<L>(a0, a.w_in, rin, lane);
     tile_act_w<L>(a0, a.act, sx, lane);
+    degn = a.rowptr[dn + 1] - a.rowptr[dn];
     tile_load_vec<L>(a1, a.layers[1].b, h);
     tile_gemm_b3<L>(a1, a.layers[1].w, a0, lane);
     tile_act_w<L>(a1, a.act, sx, lane);
@@ -913,10 +930,12 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const WgradBatch jobs, int64
   }
 }
 // dW[o][col0 + k] += sum_g part[g][o][k];  db[o] += sum_g cpart[g][o], per job (blockIdx.y).  A workgroup takes 64
-// consecutive outputs and four interleaved subsequences of g, combined in a fixed order (deterministic).
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradBatch jobs, const float* __restrict__ part_all,
-                                                           const float* __restrict__ cpart_all, int G, int L) {
-  __shared__ float sm[4][64];
+// consecutive outputs and kRedSlices interleaved subsequences of g (a handful of independent loads a thread instead of
+// one long latency-bound loop), combined in a fixed order (deterministic).
+constexpr int kRedSlices = 16;
+__global__ __launch_bounds__(64 * kRedSlices) void wgrad_reduce_kernel(const WgradBatch jobs, const float* __restrict__ part_all,
+                                                                       const float* __restrict__ cpart_all, int G, int L) {
+  __shared__ float sm[kRedSlices][64];
   const WgradJob jb = jobs.job[blockIdx.y];
   const int LL = L * L;
   const float* part = part_all + static_cast<int64_t>(blockIdx.y) * G * LL;
@@ -925,15 +944,19 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradBatch jobs
   const bool is_w = i < LL, is_b = !is_w && i < LL + L && jb.db;
   float s = 0.f;
   if (is_w) {
-    for (int g = sl; g < G; g += 4) s += part[static_cast<int64_t>(g) * LL + i];
+#pragma unroll 4
+    for (int g = sl; g < G; g += kRedSlices) s += part[static_cast<int64_t>(g) * LL + i];
   } else if (is_b) {
-    for (int g = sl; g < G; g += 4) s += cpart[static_cast<int64_t>(g) * L + (i - LL)];
+#pragma unroll 4
+    for (int g = sl; g < G; g += kRedSlices) s += cpart[static_cast<int64_t>(g) * L + (i - LL)];
   }
   sm[sl][threadIdx.x & 63] = s;
   __syncthreads();
   if (sl == 0) {
     const int t = threadIdx.x;
-    const float tot = ((sm[0][t] + sm[1][t]) + sm[2][t]) + sm[3][t];
+    float tot = sm[0][t];
+#pragma unroll
+    for (int k = 1; k < kRedSlices; ++k) tot += sm[k][t];
     if (is_w)
       jb.dW[static_cast<int64_t>(i / L) * jb.ld + jb.col0 + (i % L)] += tot;
     else if (is_b)
@@ -1191,7 +1214,7 @@ hipError_t launch_edge_bwd_fused(int L, const ChainBwdArgs& a, float* wpart, flo
 }
 hipError_t launch_wgrad_reduce(int L, const WgradBatch& b, const float* part, const float* cpart, int G, hipStream_t s) {
   if (b.n == 0) return hipSuccess;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(L * L + L, 64), b.n), dim3(256), 0, s, b, part, cpart, G, L);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(L * L + L, 64), b.n), dim3(64 * kRedSlices), 0, s, b, part, cpart, G, L);
   return hipGetLastError();
 }
 hipError_t launch_colpart_reduce(const float* part, int G, int L, float* out0, int n0, float* out1, int n1, hipStream_t s) {
@@ -1274,7 +1297,7 @@ static hipError_t launch_wgrad_t(const WgradBatch& b, float* part, float* cpart,
   hipLaunchKernelGGL((wgrad_kernel<L, B3>), dim3(G, b.n), dim3(512), lds, s, b, chunk, part, cpart);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(L * L + L, 64), b.n), dim3(256), 0, s, b, part, cpart, G, L);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(L * L + L, 64), b.n), dim3(64 * kRedSlices), 0, s, b, part, cpart, G, L);
   return hipGetLastError();
 }
 hipError_t launch_wgrad_batch(int L, const WgradBatch& b, float* part, float* cpart, hipStream_t s) {
