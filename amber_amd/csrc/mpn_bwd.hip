@@ -563,6 +563,23 @@ __global__ __launch_bounds__(kBlock, 1) void edge_bwd_fused_kernel(const ChainBw
 #pragma unroll
       for (int r = 0; r < 16; ++r) g0[i][j][r] = g1[i][j][r] = 0.f;
   const bool ln = a.layer_norm == AMBER_MODE_INNER, res = a.residual == AMBER_MODE_INNER;
+  // W1, W1^T and W0e^T (bf16x3 operand order) live in LDS behind the stages: read per tile from L2 they cost a tenth of
+  // the training step, and their loads queue behind the tile's stores
+  constexpr int WF = L * L * 3 / 2;
+  float* wl = lds_fused + 2 * kWavesPerBlock * SF;
+  {
+    const float* srcs[3] = {a.layers[1].w, a.wT[1], a.wT_in};
+#pragma unroll
+    for (int mtx = 0; mtx < 3; ++mtx)
+      for (int i = threadIdx.x; i < WF / 4; i += kBlock)
+        reinterpret_cast<f32x4*>(wl + mtx * WF)[i] = reinterpret_cast<const f32x4*>(srcs[mtx])[i];
+    __syncthreads();
+  }
+  Tile<L> keep;
+  tile_zero<L>(keep);
+  bool have_prev = false;
+  int64_t prev_p0 = 0;
+  int prev_nv = 0;
 
   const int64_t gw = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave;
   const int64_t G = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
@@ -589,7 +606,7 @@ __global__ __launch_bounds__(kBlock, 1) void edge_bwd_fused_kernel(const ChainBw
     const bool rowok = c < nvalid;
     const int d = dn, sidx = sn, deg = degn;
     // ---- recompute: a0 = act(P_s[src] + P_d[dst] + W0e e), a1 = act(W1 a0 + b1) ----
-    Tile<L> rin, a0, a1, dr, keep;
+    Tile<L> rin, a0, a1, dr;
     tile_load_row<L>(rin, a.rin, p, h);
     tile_load_row<L>(a0, a.Ps, sidx, h);
     tile_add_row<L>(a0, a.Pd, d, h);
@@ -599,11 +616,16 @@ __global__ __launch_bounds__(kBlock, 1) void edge_bwd_fused_kernel(const ChainBw
       dn = a.dst[q];
       sn = a.src[q];
     }
+    // W0e comes from L2 (its loads go out here, ahead of the previous tile's stores); the other three matrices are in LDS
     tile_gemm_b3<L>(a0, a.w_in, rin, lane);
+    if (have_prev) {
+      stage_store_rows<L>(sx, a.DH[0], prev_p0, prev_nv, nullptr, lane);
+      tile_store_w<L>(sx, keep, a.dio, prev_p0, prev_nv, lane);
+    }
     tile_act_w<L>(a0, a.act, sx, lane);
     degn = a.rowptr[dn + 1] - a.rowptr[dn];
     tile_load_vec<L>(a1, a.layers[1].b, h);
-    tile_gemm_b3<L>(a1, a.layers[1].w, a0, lane);
+    tile_gemm_b3<L>(a1, wl, a0, lane);
     tile_act_w<L>(a1, a.act, sx, lane);
     // ---- gradient at the module's output: dE + DM[dst] / deg(dst) ----
     {
@@ -639,7 +661,7 @@ __global__ __launch_bounds__(kBlock, 1) void edge_bwd_fused_kernel(const ChainBw
 #pragma unroll
       for (int fb = 0; fb < NFB; ++fb) dr.a[fb] = (dr.a[fb] - m1 - xh.a[fb] * m2) * rstd;
     }
-    keep = dr;  // the residual term of the input gradient
+    Tile<L> keep_now = dr;  // the residual term of the input gradient
     // ---- layer 1: DH1 = dr * act'(a1);  dW1 += DH1^T a0, db1 += column sums;  dr = W1^T DH1 ----
     tile_mul_dact<L>(dr, a1, a.act);
     wave_sync();
@@ -654,18 +676,26 @@ __global__ __launch_bounds__(kBlock, 1) void edge_bwd_fused_kernel(const ChainBw
     tile_wgrad_b3<L>(g1, sx, sy, c, h);
     Tile<L> nd;
     tile_zero<L>(nd);
-    tile_gemm_b3<L>(nd, a.wT[1], dr, lane);
+    tile_gemm_b3<L>(nd, wl + WF, dr, lane);
     // ---- layer 0: DH0 = nd * act'(a0);  dW0e += DH0^T e;  gradient at e = W0e^T DH0 (+ the residual term) ----
     tile_mul_dact<L>(nd, a0, a.act);
     wave_sync();
     tile_stage<L>(sx, nd, c, h);
     tile_stage<L>(sy, rin, c, h);
     wave_sync();
-    stage_store_rows<L>(sx, a.DH[0], p0, nvalid, nullptr, lane);
     tile_wgrad_b3<L>(g0, sx, sy, c, h);
-    if (!res) tile_zero<L>(keep);
-    tile_gemm_b3<L>(keep, a.wT_in, nd, lane);
-    tile_store_w<L>(sx, keep, a.dio, p0, nvalid, lane);
+    if (!res) tile_zero<L>(keep_now);
+    tile_gemm_b3<L>(keep_now, wl + 2 * WF, nd, lane);
+    keep = keep_now;
+    // DH0 (still staged in sx) and the input gradient (keep) are stored at the top of the wave's next tile, behind that
+    // tile's loads: results return in order, so loads queued behind 16 KB of stores would wait for their acknowledgement
+    have_prev = true;
+    prev_p0 = p0;
+    prev_nv = nvalid;
+  }
+  if (have_prev) {
+    stage_store_rows<L>(sx, a.DH[0], prev_p0, prev_nv, nullptr, lane0);
+    tile_store_w<L>(sx, keep, a.dio, prev_p0, prev_nv, lane0);
   }
   // ---- per-workgroup partials: column sums first, then the two products, waves added in wave order through LDS ----
   __syncthreads();
@@ -1198,9 +1228,10 @@ int edge_bwd_fused_grid(int64_t rows) {
 }
 template <int L>
 static hipError_t launch_edge_bwd_fused_t(const ChainBwdArgs& a, float* wpart, float* cpart, hipStream_t s) {
-  const size_t lds = sizeof(float) * 2 * kWavesPerBlock * stage_floats<L>();
+  const size_t lds = sizeof(float) * (2 * kWavesPerBlock * stage_floats<L>() + 3 * (L * L * 3 / 2));  // stages + three matrices
   static_assert(sizeof(float) * 2 * kWavesPerBlock * stage_floats<L>() >= sizeof(float) * 3 * (L / 32) * (L / 32) * 16 * 64,
                 "the end-of-kernel reduction reuses the stages");
+  static_assert(sizeof(float) * (2 * kWavesPerBlock * stage_floats<L>() + 3 * (L * L * 3 / 2)) <= 160 * 1024, "LDS of a CU");
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(edge_bwd_fused_kernel<L>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      static_cast<int>(lds));
   if (e != hipSuccess) return e;
