@@ -665,8 +665,10 @@ BwdWorkspace carve_bwd(const AmberMpnDesc& d, int64_t N, int64_t E, void* base) 
     w.AE[l] = l < ne ? take(eb) : nullptr;
     w.DHE[l] = l < ne ? take(eb) : nullptr;
   }
-  w.gpart = take(align256(sizeof(float) * kWgradMaxChunks * L * L));
-  w.cpart = take(align256(sizeof(float) * kWgradMaxChunks * L));
+  // split-K partial products, or the fused backward kernels' per-workgroup partials
+  const size_t nparts = kWgradMaxChunks > kFusedMaxProducts * kFusedBwdBlocks ? kWgradMaxChunks : kFusedMaxProducts * kFusedBwdBlocks;
+  w.gpart = take(align256(sizeof(float) * nparts * L * L));
+  w.cpart = take(align256(sizeof(float) * nparts * L));
   w.lnpart = take(align256(sizeof(float) * kBwdMaxBlocks * 2 * L));
   w.pnpart = dnorm ? take(align256(sizeof(float) * kBwdMaxBlocks * kBwdWavesPerBlock * d.decoder_layers * 2 * L)) : nullptr;
   w.epart = take(align256(sizeof(float) * kWgradMaxChunks * L * 65));
@@ -849,15 +851,22 @@ int backward_impl(const AmberMpnDesc* desc, const float* params, const float* pa
       a.dio = w.dX;
       a.dm_out = w.DM;
       a.part = ln ? w.lnpart : nullptr;
-      HIP_TRY(launch_chain_bwd(L, a, s), "node backward kernel");
-      if (ln) HIP_TRY(launch_colpart_reduce(w.lnpart, gn, L, g + lay.ng[step], L, g + lay.nb[step], L, s), "node LayerNorm gradient");
       WgradBatch wb{};
       wb.split = split;
       wb.M = N;
       wjob(wb, w.DHN[0], x_in, g + mn.W[0], 2 * L, 0, g + mn.B[0]);  // dW0x, db0
       wjob(wb, w.DHN[0], mean_in, g + mn.W[0], 2 * L, L, nullptr);   // dW0a
       for (int l = 1; l < nl; ++l) wjob(wb, w.DHN[l], w.AN[l - 1], g + mn.W[l], L, 0, g + mn.B[l]);
-      HIP_TRY(launch_wgrad_batch(L, wb, w.gpart, w.cpart, s), "node weight gradients");
+      if (node_bwd_fused_supported(L, a) && !env_switches().no_fused_backward) {
+        const int gf = edge_bwd_fused_grid(N);
+        HIP_TRY(launch_node_bwd_fused(L, a, w.gpart, w.cpart, s), "fused node backward kernel");
+        if (ln) HIP_TRY(launch_colpart_reduce(w.lnpart, gf, L, g + lay.ng[step], L, g + lay.nb[step], L, s), "node LayerNorm gradient");
+        HIP_TRY(launch_wgrad_reduce(L, wb, w.gpart, w.cpart, gf, s), "node weight gradients (reduction)");
+      } else {
+        HIP_TRY(launch_chain_bwd(L, a, s), "node backward kernel");
+        if (ln) HIP_TRY(launch_colpart_reduce(w.lnpart, gn, L, g + lay.ng[step], L, g + lay.nb[step], L, s), "node LayerNorm gradient");
+        HIP_TRY(launch_wgrad_batch(L, wb, w.gpart, w.cpart, s), "node weight gradients");
+      }
     }
     if (E == 0) continue;
     // ---- edge module: e' = LN(MLP([x_s, x_d, e]) + e), first layer split into P_s[src] + P_d[dst] + W0e e ----

@@ -472,6 +472,39 @@ DEVINL void tile_wgrad_b3(f32x16 (&acc)[L / 32][L / 32], const float* sx, const 
   }
 }
 
+// one per-wave product (accumulator tiles g) of the workgroup's waves added in wave order through LDS and stored as the
+// workgroup's partial P[out feature][in feature]; every wave of the workgroup calls it
+template <int L>
+DEVINL void block_product_store(const f32x16 (&g)[L / 32][L / 32], float* lds, int wave, int lane, float* __restrict__ P) {
+  constexpr int NFB = L / 32, TF = NFB * NFB * 16 * 64;
+  const int c = lane & 31, h = lane >> 5;
+  if (wave > 0) {
+    float* mine = lds + static_cast<size_t>(wave - 1) * TF;
+#pragma unroll
+    for (int i = 0; i < NFB; ++i)
+#pragma unroll
+      for (int j = 0; j < NFB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mine[((i * NFB + j) * 16 + r) * 64 + lane] = g[i][j][r];
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int i = 0; i < NFB; ++i)
+#pragma unroll
+      for (int j = 0; j < NFB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = g[i][j][r];
+#pragma unroll
+          for (int w = 1; w < kWavesPerBlock; ++w) v += lds[static_cast<size_t>(w - 1) * TF + ((i * NFB + j) * 16 + r) * 64 + lane];
+          const int m = (r & 3) + 8 * (r >> 2) + 4 * h;  // output feature within block i; input feature 32 j + c
+          P[(32 * i + m) * L + 32 * j + c] = v;
+        }
+  }
+  __syncthreads();
+}
+
 template <int L>
 __global__ __launch_bounds__(kBlock, 1) void edge_bwd_fused_kernel(const ChainBwdArgs a, const int64_t ntiles, float* __restrict__ wpart,
                                                                     float* __restrict__ cpart) {
@@ -653,38 +686,170 @@ __global__ __launch_bounds__(kBlock, 1) void edge_bwd_fused_kernel(const ChainBw
     }
     __syncthreads();
   }
-  constexpr int TF = NFB * NFB * 16 * 64;
-  const int lane = lane0, c = lane & 31, h = lane >> 5;
+  block_product_store<L>(g0, lds_fused, wave, lane0, wpart + (static_cast<int64_t>(0) * gridDim.x + blockIdx.x) * L * L);
+  block_product_store<L>(g1, lds_fused, wave, lane0, wpart + (static_cast<int64_t>(1) * gridDim.x + blockIdx.x) * L * L);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// fused node backward (same conditions as the fused edge backward): the node-mode chain and its three weight-gradient
+// products dW0x = DH0^T x, dW0a = DH0^T m, dW1 = DH1^T A0 (192 accumulator registers at latent 64), one wave per SIMD.
+// An airfoil-sized batch has two node tiles a wave: the launch is two tiles' latency instead of the chain kernel's tile
+// (store, hand over, re-read) plus a split-K launch.  Matrices come from L2 (with so few tiles a workgroup would load an
+// LDS copy for nothing).  cpart slots: job 0 (dW0x) carries db0, job 2 (dW1) db1.
+// ---------------------------------------------------------------------------------------------------
+template <int L>
+__global__ __launch_bounds__(kBlock, 1) void node_bwd_fused_kernel(const ChainBwdArgs a, const int64_t ntiles, float* __restrict__ wpart,
+                                                                    float* __restrict__ cpart) {
+  extern __shared__ __attribute__((aligned(16))) float lds_fused[];
+  constexpr int NFB = L / 32, SF = stage_floats<L>(), ST = stage_stride<L>();
+  const int lane0 = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float* sx = lds_fused + (2 * wave) * SF;
+  float* sy = sx + SF;
+  constexpr int FPL = (L + 63) / 64;
+  const bool active = lane0 * FPL < L;
+  const int fo = active ? lane0 * FPL : 0;
+  float ps0[FPL], ps1[FPL], ps2[FPL], ps3[FPL];
 #pragma unroll
-  for (int mtx = 0; mtx < 2; ++mtx) {
-    f32x16 (&g)[NFB][NFB] = mtx == 0 ? g0 : g1;
-    if (wave > 0) {
-      float* mine = lds_fused + static_cast<size_t>(wave - 1) * TF;
+  for (int q = 0; q < FPL; ++q) ps0[q] = ps1[q] = ps2[q] = ps3[q] = 0.f;
+  f32x16 gx[NFB][NFB], gm[NFB][NFB], g1[NFB][NFB];
 #pragma unroll
-      for (int i = 0; i < NFB; ++i)
+  for (int i = 0; i < NFB; ++i)
 #pragma unroll
-        for (int j = 0; j < NFB; ++j)
+    for (int j = 0; j < NFB; ++j)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) mine[((i * NFB + j) * 16 + r) * 64 + lane] = g[i][j][r];
+      for (int r = 0; r < 16; ++r) gx[i][j][r] = gm[i][j][r] = g1[i][j][r] = 0.f;
+  const bool ln = a.layer_norm == AMBER_MODE_INNER, res = a.residual == AMBER_MODE_INNER;
+  const int64_t gw = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave;
+  const int64_t G = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
+  for (int64_t tile = gw; tile < ntiles; tile += G) {
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const int c = lane & 31, h = lane >> 5;
+    const int64_t p0 = tile * kTile;
+    const int nvalid = (a.rows - p0) < kTile ? static_cast<int>(a.rows - p0) : kTile;
+    int64_t p = p0 + c;
+    if (p > a.rows - 1) p = a.rows - 1;
+    const bool rowok = c < nvalid;
+    // ---- recompute: a0 = act(b0 + W0x x + W0a m), a1 = act(W1 a0 + b1) ----
+    Tile<L> x, a0, a1, dr;
+    tile_load_row<L>(x, a.rin, p, h);
+    tile_load_vec<L>(a0, a.b0, h);
+    {
+      Tile<L> m;
+      tile_load_row<L>(m, a.m, p, h);
+      tile_load_row<L>(dr, a.dio, p, h);  // the incoming gradient, asked for early
+      tile_gemm_b3<L>(a0, a.w_in, x, lane);
+      tile_gemm_b3<L>(a0, a.w_m, m, lane);
+    }
+    tile_act_w<L>(a0, a.act, sx, lane);
+    tile_load_vec<L>(a1, a.layers[1].b, h);
+    tile_gemm_b3<L>(a1, a.layers[1].w, a0, lane);
+    tile_act_w<L>(a1, a.act, sx, lane);
+    if (!rowok) tile_zero<L>(dr);
+    // ---- LayerNorm backward (as in chain_bwd_kernel) ----
+    if (ln) {
+      Tile<L> xh = a1;
+      if (res) tile_add<L>(xh, x);
+      const float rstd = tile_ln_xhat<L>(xh, a.eps);
+      tile_colsum_acc<L, FPL>(sx, dr, ps1, active, fo, lane);  // d beta
+      const f32x4* gp = reinterpret_cast<const f32x4*>(a.gamma) + h;
+      wave_sync();
+      {
+        f32x4* sp = reinterpret_cast<f32x4*>(sx + c * ST) + h;
+#pragma unroll
+        for (int j = 0; j < L / 8; ++j) sp[2 * j] = tile_get_chunk<L>(dr, j) * tile_get_chunk<L>(xh, j);
+      }
+      wave_sync();
+      if (active) {
+        for (int r = 0; r < kTile; ++r)
+#pragma unroll
+          for (int q = 0; q < FPL; ++q) ps0[q] += sx[r * ST + fo + q];  // d gamma
+      }
+#pragma unroll
+      for (int j = 0; j < L / 8; ++j) tile_set_chunk<L>(dr, j, tile_get_chunk<L>(dr, j) * gp[2 * j]);
+      const float m1 = tile_row_sum<L>(dr) * (1.0f / L);
+      const float m2 = tile_row_dot<L>(dr, xh) * (1.0f / L);
+#pragma unroll
+      for (int fb = 0; fb < NFB; ++fb) dr.a[fb] = (dr.a[fb] - m1 - xh.a[fb] * m2) * rstd;
+    }
+    Tile<L> keep = dr;  // the residual term of the input gradient
+    // ---- layer 1: DH1 = dr * act'(a1);  dW1 += DH1^T a0, db1 += column sums;  nd = W1^T DH1 ----
+    tile_mul_dact<L>(dr, a1, a.act);
+    wave_sync();
+    tile_stage<L>(sx, dr, c, h);
+    tile_stage<L>(sy, a0, c, h);
+    wave_sync();
+    if (active) {
+      for (int r = 0; r < kTile; ++r)
+#pragma unroll
+        for (int q = 0; q < FPL; ++q) ps2[q] += sx[r * ST + fo + q];
+    }
+    tile_wgrad_b3<L>(g1, sx, sy, c, h);
+    Tile<L> nd;
+    tile_zero<L>(nd);
+    tile_gemm_b3<L>(nd, a.wT[1], dr, lane);
+    // ---- layer 0: DH0 = nd * act'(a0);  dW0x += DH0^T x, dW0a += DH0^T m, db0 += column sums ----
+    tile_mul_dact<L>(nd, a0, a.act);
+    {
+      Tile<L> m;
+      tile_load_row<L>(m, a.m, p, h);  // again (L2): cheaper than 32 registers held across the tile
+      wave_sync();
+      tile_stage<L>(sx, nd, c, h);
+      tile_stage<L>(sy, x, c, h);
+      wave_sync();
+      if (active) {
+        for (int r = 0; r < kTile; ++r)
+#pragma unroll
+          for (int q = 0; q < FPL; ++q) ps3[q] += sx[r * ST + fo + q];
+      }
+      tile_wgrad_b3<L>(gx, sx, sy, c, h);
+      wave_sync();
+      tile_stage<L>(sy, m, c, h);
+      wave_sync();
+      tile_wgrad_b3<L>(gm, sx, sy, c, h);
+    }
+    // ---- gradients at the aggregate and at x (+ the residual term) ----
+    {
+      Tile<L> dm;
+      tile_zero<L>(dm);
+      tile_gemm_b3<L>(dm, a.wT_m, nd, lane);
+      tile_store_w<L>(sy, dm, a.dm_out, p0, nvalid, lane);
+    }
+    if (!res) tile_zero<L>(keep);
+    tile_gemm_b3<L>(keep, a.wT_in, nd, lane);
+    tile_store_w<L>(sx, keep, a.dio, p0, nvalid, lane);
+  }
+  // ---- per-workgroup partials ----
+  __syncthreads();
+  {
+    float* red = lds_fused;  // [wave][4][L]
+    if (active) {
+#pragma unroll
+      for (int q = 0; q < FPL; ++q) {
+        red[(wave * 4 + 0) * L + fo + q] = ps0[q];
+        red[(wave * 4 + 1) * L + fo + q] = ps1[q];
+        red[(wave * 4 + 2) * L + fo + q] = ps2[q];
+        red[(wave * 4 + 3) * L + fo + q] = ps3[q];
+      }
     }
     __syncthreads();
-    if (wave == 0) {
-      float* P = wpart + (static_cast<int64_t>(mtx) * gridDim.x + blockIdx.x) * L * L;
+    for (int i = threadIdx.x; i < 4 * L; i += kBlock) {
+      float sum = red[i];
 #pragma unroll
-      for (int i = 0; i < NFB; ++i)
-#pragma unroll
-        for (int j = 0; j < NFB; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            float v = g[i][j][r];
-#pragma unroll
-            for (int w = 1; w < kWavesPerBlock; ++w) v += lds_fused[static_cast<size_t>(w - 1) * TF + ((i * NFB + j) * 16 + r) * 64 + lane];
-            const int m = (r & 3) + 8 * (r >> 2) + 4 * h;  // output feature within block i; input feature 32 j + c
-            P[(32 * i + m) * L + 32 * j + c] = v;
-          }
+      for (int w = 1; w < kWavesPerBlock; ++w) sum += red[w * 4 * L + i];
+      if (i < 2 * L) {
+        if (a.part) a.part[static_cast<int64_t>(blockIdx.x) * 2 * L + i] = sum;
+      } else if (i < 3 * L) {
+        cpart[(static_cast<int64_t>(2) * gridDim.x + blockIdx.x) * L + (i - 2 * L)] = sum;  // job 2 (dW1): db1
+      } else {
+        cpart[(static_cast<int64_t>(0) * gridDim.x + blockIdx.x) * L + (i - 3 * L)] = sum;  // job 0 (dW0x): db0
+      }
     }
     __syncthreads();
   }
+  block_product_store<L>(gx, lds_fused, wave, lane0, wpart + (static_cast<int64_t>(0) * gridDim.x + blockIdx.x) * L * L);
+  block_product_store<L>(gm, lds_fused, wave, lane0, wpart + (static_cast<int64_t>(1) * gridDim.x + blockIdx.x) * L * L);
+  block_product_store<L>(g1, lds_fused, wave, lane0, wpart + (static_cast<int64_t>(2) * gridDim.x + blockIdx.x) * L * L);
 }
 
 // out0[f] += sum_g part[g][0][f] (f < n0), out1[f] += sum_g part[g][1][f] (f < n1): one wave per output, lane j adds
@@ -1173,6 +1338,26 @@ hipError_t launch_edge_bwd_fused(int L, const ChainBwdArgs& a, float* wpart, flo
   if (a.rows == 0) return hipSuccess;
   if (!edge_bwd_fused_supported(L, a)) return hipErrorInvalidValue;
   return L == 32 ? launch_edge_bwd_fused_t<32>(a, wpart, cpart, s) : launch_edge_bwd_fused_t<64>(a, wpart, cpart, s);
+}
+bool node_bwd_fused_supported(int L, const ChainBwdArgs& a) {
+  return (L == 32 || L == 64) && a.split && a.mode == AMBER_BWD_NODE && a.m != nullptr && a.nl == 2 && a.residual != AMBER_MODE_OUTER &&
+         a.layer_norm != AMBER_MODE_OUTER;
+}
+template <int L>
+static hipError_t launch_node_bwd_fused_t(const ChainBwdArgs& a, float* wpart, float* cpart, hipStream_t s) {
+  const size_t lds = sizeof(float) * 2 * kWavesPerBlock * stage_floats<L>();
+  static_assert(sizeof(float) * 2 * kWavesPerBlock * stage_floats<L>() >= sizeof(float) * 3 * (L / 32) * (L / 32) * 16 * 64,
+                "the end-of-kernel reduction reuses the stages");
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(node_bwd_fused_kernel<L>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     static_cast<int>(lds));
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(node_bwd_fused_kernel<L>, dim3(edge_bwd_fused_grid(a.rows)), dim3(kBlock), lds, s, a, cdiv(a.rows, kTile), wpart, cpart);
+  return hipGetLastError();
+}
+hipError_t launch_node_bwd_fused(int L, const ChainBwdArgs& a, float* wpart, float* cpart, hipStream_t s) {
+  if (a.rows == 0) return hipSuccess;
+  if (!node_bwd_fused_supported(L, a)) return hipErrorInvalidValue;
+  return L == 32 ? launch_node_bwd_fused_t<32>(a, wpart, cpart, s) : launch_node_bwd_fused_t<64>(a, wpart, cpart, s);
 }
 hipError_t launch_wgrad_reduce(int L, const WgradBatch& b, const float* part, const float* cpart, int G, hipStream_t s) {
   if (b.n == 0) return hipSuccess;

@@ -224,6 +224,10 @@ bool edge_bwd_fused_supported(int L, const ChainBwdArgs& a);
 int edge_bwd_fused_grid(int64_t rows);
 // wpart: [2][grid][L*L] partial products (dW0e, dW1), cpart: [2][grid][L] (slot 1: db1), a.part: [grid][2][L] LayerNorm sums
 hipError_t launch_edge_bwd_fused(int L, const ChainBwdArgs& a, float* wpart, float* cpart, hipStream_t s);
+// the same for the node module: wpart [3][grid][L*L] (dW0x, dW0a, dW1), cpart [3][grid][L] (slot 0: db0, slot 2: db1)
+constexpr int kFusedMaxProducts = 3;
+bool node_bwd_fused_supported(int L, const ChainBwdArgs& a);
+hipError_t launch_node_bwd_fused(int L, const ChainBwdArgs& a, float* wpart, float* cpart, hipStream_t s);
 hipError_t launch_chain_bwd(int L, const ChainBwdArgs& a, hipStream_t s);
 hipError_t launch_colpart_reduce(const float* part, int G, int L, float* out0, int n0, float* out1, int n1, hipStream_t s);
 // the same over partials that lie gstride floats apart (per-layer slots of pn_part)
