@@ -731,11 +731,12 @@ __global__ __launch_bounds__(kBlock, 1) void node_bwd_fused_kernel(const ChainBw
     if (p > a.rows - 1) p = a.rows - 1;
     const bool rowok = c < nvalid;
     // ---- recompute: a0 = act(b0 + W0x x + W0a m), a1 = act(W1 a0 + b1) ----
-    Tile<L> x, a0, a1, dr;
-    tile_load_row<L>(x, a.rin, p, h);
+    // x and m are read again where they are needed later (L2): cheaper than 64 registers held across the tile
+    Tile<L> a0, a1, dr;
     tile_load_vec<L>(a0, a.b0, h);
     {
-      Tile<L> m;
+      Tile<L> x, m;
+      tile_load_row<L>(x, a.rin, p, h);
       tile_load_row<L>(m, a.m, p, h);
       tile_load_row<L>(dr, a.dio, p, h);  // the incoming gradient, asked for early
       tile_gemm_b3<L>(a0, a.w_in, x, lane);
@@ -749,7 +750,7 @@ __global__ __launch_bounds__(kBlock, 1) void node_bwd_fused_kernel(const ChainBw
     // ---- LayerNorm backward (as in chain_bwd_kernel) ----
     if (ln) {
       Tile<L> xh = a1;
-      if (res) tile_add<L>(xh, x);
+      if (res) tile_add_row<L>(xh, a.rin, p, h);
       const float rstd = tile_ln_xhat<L>(xh, a.eps);
       tile_colsum_acc<L, FPL>(sx, dr, ps1, active, fo, lane);  // d beta
       const f32x4* gp = reinterpret_cast<const f32x4*>(a.gamma) + h;
@@ -791,8 +792,9 @@ __global__ __launch_bounds__(kBlock, 1) void node_bwd_fused_kernel(const ChainBw
     // ---- layer 0: DH0 = nd * act'(a0);  dW0x += DH0^T x, dW0a += DH0^T m, db0 += column sums ----
     tile_mul_dact<L>(nd, a0, a.act);
     {
-      Tile<L> m;
-      tile_load_row<L>(m, a.m, p, h);  // again (L2): cheaper than 32 registers held across the tile
+      Tile<L> x, m;
+      tile_load_row<L>(x, a.rin, p, h);
+      tile_load_row<L>(m, a.m, p, h);
       wave_sync();
       tile_stage<L>(sx, nd, c, h);
       tile_stage<L>(sy, x, c, h);
