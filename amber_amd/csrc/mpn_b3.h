@@ -78,4 +78,52 @@ DEVINL void tile_gemm_b3(Tile<L>& acc, const float* __restrict__ wpacked, const 
   }
 }
 
+// The same contraction with the matrix streamed ONCE per workgroup: a k-step's weight pieces (L/32 * 3 * 1 KB) go from
+// L2 into a double-buffered LDS window by all threads of the workgroup and every wave takes its operands from there.  At
+// latent 128 a wave that reads its matrices itself pulls 96 KB per contraction and 32-row tile through L2 - the chain
+// kernel's bound at config 5's size (120 GB a launch).  EVERY wave of the workgroup must make the call (one barrier per
+// k-step): the caller's control flow around it has to be workgroup-uniform.
+template <int L>
+DEVINL void tile_gemm_b3_shared(Tile<L>& acc, const float* __restrict__ wpacked, const Tile<L>& in, int lane, u32x4* wbuf) {
+  constexpr int NFB = L / 32, NS = L / 16, STEP = NFB * 3 * 64, PER = STEP / kBlock;
+  static_assert(STEP % kBlock == 0, "a k-step's pieces divide over the workgroup's threads");
+  const u32x4* __restrict__ wg = reinterpret_cast<const u32x4*>(wpacked);
+  // from the caller's lane id, which is opaque per tile: with threadIdx.x itself the weight loads are invariant of the tile loop
+  // and the compiler hoists all of them out of it (hundreds of registers)
+  const int tid = (static_cast<int>(threadIdx.x) & ~63) | lane;
+  u32x4 r[PER];
+#pragma unroll
+  for (int k = 0; k < PER; ++k) r[k] = wg[k * kBlock + tid];
+#pragma unroll
+  for (int k = 0; k < PER; ++k) wbuf[k * kBlock + tid] = r[k];  // window 0 is free: the previous call ended with a barrier
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    if (s + 1 < NS) {
+#pragma unroll
+      for (int k = 0; k < PER; ++k) r[k] = wg[(s + 1) * STEP + k * kBlock + tid];
+    }
+    float v[8];
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) v[jj] = in.a[s >> 1][8 * (s & 1) + jj];
+    u32x4 x[3];
+    split3(v, x);
+    const u32x4* wl = wbuf + (s & 1) * STEP + lane;
+    u32x4 wf[NFB][3];
+#pragma unroll
+    for (int fb = 0; fb < NFB; ++fb)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) wf[fb][q] = wl[(fb * 3 + q) * 64];
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+#pragma unroll
+      for (int fb = 0; fb < NFB; ++fb) acc.a[fb] = mfma_b(wf[fb][kB3W[q]], x[kB3X[q]], acc.a[fb]);
+    if (s + 1 < NS) {
+#pragma unroll
+      for (int k = 0; k < PER; ++k) wbuf[((s + 1) & 1) * STEP + k * kBlock + tid] = r[k];
+    }
+    __syncthreads();  // window (s + 1) & 1 is complete, and window s & 1 has been read by every wave
+  }
+}
+
 }  // namespace amber

@@ -188,10 +188,22 @@ __global__ __launch_bounds__(kBlock, L <= 64 ? 2 : 1) void chain_bwd_kernel(cons
   float ps0[FPL], ps1[FPL];
 #pragma unroll
   for (int q = 0; q < FPL; ++q) ps0[q] = ps1[q] = 0.f;
+  // latent 128 on bf16x3 operands: the matrices are streamed once per workgroup through an LDS window (tile_gemm_b3_shared);
+  // its barriers need every wave of the workgroup at every contraction, so the tile loop below is workgroup-uniform (a
+  // wave past the last tile works on clamped rows with nvalid <= 0: nothing of it is stored or summed)
+  constexpr bool SHARED_W = B3 && L == 128;
+  __shared__ __attribute__((aligned(16))) u32x4 wwin[SHARED_W ? 2 * (L / 32) * 3 * 64 : 1];
+#define GEMM(ACC, W, IN, LANE)                                 \
+  do {                                                         \
+    if constexpr (SHARED_W)                                    \
+      tile_gemm_b3_shared<L>(ACC, W, IN, LANE, wwin);          \
+    else                                                       \
+      tile_gemm_sel<L, B3>(ACC, W, IN, LANE);                  \
+  } while (0)
 
   const int64_t gw = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave;
   const int64_t G = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
-  for (int64_t tile = gw; tile < ntiles; tile += G) {
+  for (int64_t tile = gw; tile - wave < ntiles; tile += G) {
     // The lane id is re-derived from an opaque copy in every iteration: with a loop-invariant lane id the weight tiles,
     // biases and LayerNorm parameters are loop-invariant loads, and hoisted out of the tile loop they occupy (and spill)
     // hundreds of registers.
@@ -201,7 +213,7 @@ __global__ __launch_bounds__(kBlock, L <= 64 ? 2 : 1) void chain_bwd_kernel(cons
 #endif
     const int c = lane & 31, h = lane >> 5;
     const int64_t p0 = tile * kTile;
-    const int nvalid = (a.rows - p0) < kTile ? static_cast<int>(a.rows - p0) : kTile;
+    const int nvalid = (a.rows - p0) < kTile ? static_cast<int>(a.rows - p0 > 0 ? a.rows - p0 : 0) : kTile;
     int64_t p = p0 + c;
     if (p > a.rows - 1) p = a.rows - 1;  // rows beyond the end repeat the last row; their gradient is zeroed below
     const bool rowok = c < nvalid;
@@ -228,13 +240,13 @@ __global__ __launch_bounds__(kBlock, L <= 64 ? 2 : 1) void chain_bwd_kernel(cons
           const int s = a.src[p];
           tile_load_row<L>(cur, a.Ps, s, h);
           tile_add_row<L>(cur, a.Pd, d, h);
-          tile_gemm_sel<L, B3>(cur, a.w_in, rin, lane);
+          GEMM(cur, a.w_in, rin, lane);
         } else {
           tile_load_vec<L>(cur, a.b0, h);
-          tile_gemm_sel<L, B3>(cur, a.w_in, rin, lane);
+          GEMM(cur, a.w_in, rin, lane);
           if (has_m) {
             tile_load_row<L>(rin, a.m, p, h);
-            tile_gemm_sel<L, B3>(cur, a.w_m, rin, lane);
+            GEMM(cur, a.w_m, rin, lane);
           }
         }
       }
@@ -252,7 +264,7 @@ __global__ __launch_bounds__(kBlock, L <= 64 ? 2 : 1) void chain_bwd_kernel(cons
         tile_store_w<L>(stage, cur, a.A[l - 1], p0, nvalid, lane);  // input of layer l: needed by dW_l and by act' below
         Tile<L> nxt;
         tile_load_vec<L>(nxt, a.layers[l].b, h);
-        tile_gemm_sel<L, B3>(nxt, a.layers[l].w, cur, lane);
+        GEMM(nxt, a.layers[l].w, cur, lane);
         tile_act_w<L>(nxt, a.act, stage, lane);
         cur = nxt;
         if constexpr (EXT) {
@@ -388,7 +400,7 @@ __global__ __launch_bounds__(kBlock, L <= 64 ? 2 : 1) void chain_bwd_kernel(cons
         tile_store_w<L>(stage, dr, a.DH[l], p0, nvalid, lane);
         Tile<L> nd;
         tile_zero<L>(nd);
-        tile_gemm_sel<L, B3>(nd, a.wT[l], dr, lane);
+        GEMM(nd, a.wT[l], dr, lane);
         dr = nd;
       }
       if (dnorm)
@@ -399,7 +411,7 @@ __global__ __launch_bounds__(kBlock, L <= 64 ? 2 : 1) void chain_bwd_kernel(cons
       tile_store_w<L>(stage, dr, a.DH[0], p0, nvalid, lane);
       if (has_m) {
         tile_zero<L>(cur);
-        tile_gemm_sel<L, B3>(cur, a.wT_m, dr, lane);
+        GEMM(cur, a.wT_m, dr, lane);
         tile_store_w<L>(stage, cur, a.dm_out, p0, nvalid, lane);
       }
       // gradient at the first layer's streamed input (+ the parked residual term; head: + what arrived at the latents)
@@ -407,7 +419,7 @@ __global__ __launch_bounds__(kBlock, L <= 64 ? 2 : 1) void chain_bwd_kernel(cons
         tile_load_row<L>(cur, a.dio, p, h);
       else
         tile_zero<L>(cur);
-      tile_gemm_sel<L, B3>(cur, a.wT_in, dr, lane);
+      GEMM(cur, a.wT_in, dr, lane);
       tile_store_w<L>(stage, cur, a.dio, p0, nvalid, lane);
     } else {
       if (a.mode == AMBER_BWD_HEAD) tile_add_row<L>(dr, a.dio, p, h);
@@ -471,6 +483,8 @@ DEVINL void tile_wgrad_b3(f32x16 (&acc)[L / 32][L / 32], const float* sx, const 
         for (int fi = 0; fi < NFB; ++fi) acc[fo][fi] = mfma_b(xp[fo][kB3W[q]], yp[fi][kB3X[q]], acc[fo][fi]);
   }
 }
+
+#undef GEMM
 
 // one per-wave product (accumulator tiles g) of the workgroup's waves added in wave order through LDS and stored as the
 // workgroup's partial P[out feature][in feature]; every wave of the workgroup calls it
