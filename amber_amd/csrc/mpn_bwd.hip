@@ -150,6 +150,19 @@ DEVINL void tile_colsum_acc(float* stage, const Tile<L>& t, float (&psum)[FPL], 
       for (int q = 0; q < FPL; ++q) psum[q] += stage[r * stage_stride<L>() + fo + q];
   }
 }
+// a tile set aside in LDS, lane-private (every lane writes and reads its own 16-byte chunks: no synchronisation needed)
+template <int L>
+DEVINL void tile_park(float* pk, const Tile<L>& t, int lane) {
+  f32x4* p = reinterpret_cast<f32x4*>(pk) + lane;
+#pragma unroll
+  for (int j = 0; j < L / 8; ++j) p[j * 64] = tile_get_chunk<L>(t, j);
+}
+template <int L>
+DEVINL void tile_unpark(Tile<L>& t, const float* pk, int lane) {
+  const f32x4* p = reinterpret_cast<const f32x4*>(pk) + lane;
+#pragma unroll
+  for (int j = 0; j < L / 8; ++j) tile_set_chunk<L>(t, j, p[j * 64]);
+}
 // make this wave's global stores visible to its own later loads issued from other lanes.  Workgroup scope: the wave's
 // stores and loads go through the same vector L1, so ordering them (s_waitcnt) is enough.  Agent scope would be wrong
 // for the purpose and ruinous in cost: MI355X's L2s are per XCD, so an agent-scope release writes the whole XCD's dirty
@@ -193,6 +206,11 @@ __global__ __launch_bounds__(kBlock, L <= 64 ? 2 : 1) void chain_bwd_kernel(cons
   // wave past the last tile works on clamped rows with nvalid <= 0: nothing of it is stored or summed)
   constexpr bool SHARED_W = B3 && L == 128;
   __shared__ __attribute__((aligned(16))) u32x4 wwin[SHARED_W ? 2 * (L / 32) * 3 * 64 : 1];
+  // the inner residual's share of the input gradient waits in LDS (PARK) instead of in the gradient buffer: a row-sized
+  // store, its hand-over and the re-read less per tile (the bf16x3 instantiations have the LDS for it: 156 KB at latent 128)
+  constexpr bool PARK = B3;
+  __shared__ __attribute__((aligned(16))) float park_all[PARK ? kWavesPerBlock * L * 32 : 4];
+  float* const pk = park_all + (PARK ? wave * L * 32 : 0);
 #define GEMM(ACC, W, IN, LANE)                                 \
   do {                                                         \
     if constexpr (SHARED_W)                                    \
@@ -351,8 +369,14 @@ __global__ __launch_bounds__(kBlock, L <= 64 ? 2 : 1) void chain_bwd_kernel(cons
     // ---- chain rule through the layers, last to first ----
     if (a.nl > 0) {
       const bool keep = a.residual == AMBER_MODE_INNER;
-      if (keep) tile_store_w<L>(stage, dr, a.dio, p0, nvalid, lane);  // parked in memory until it joins the input gradient
-      if (a.nl > 1 || res_any || dnorm) wave_global_handover();  // rows stored above are re-read by other lanes of this wave
+      if (keep) {  // set aside until it joins the input gradient
+        if constexpr (PARK)
+          tile_park<L>(pk, dr, lane);
+        else
+          tile_store_w<L>(stage, dr, a.dio, p0, nvalid, lane);
+      }
+      // rows stored above are re-read by other lanes of this wave
+      if (a.nl > 1 || dnorm || (res_any && !(PARK && keep))) wave_global_handover();
       // decoder LayerNorm behind layer l: dr arrives at n_l = LN_l(a_l) and leaves at a_l
       auto post_norm_bwd = [&](int l) {
         if constexpr (EXT) {
@@ -415,7 +439,9 @@ __global__ __launch_bounds__(kBlock, L <= 64 ? 2 : 1) void chain_bwd_kernel(cons
         tile_store_w<L>(stage, cur, a.dm_out, p0, nvalid, lane);
       }
       // gradient at the first layer's streamed input (+ the parked residual term; head: + what arrived at the latents)
-      if (res_any || a.mode == AMBER_BWD_HEAD)
+      if (PARK && keep)
+        tile_unpark<L>(cur, pk, lane);
+      else if (res_any || a.mode == AMBER_BWD_HEAD)
         tile_load_row<L>(cur, a.dio, p, h);
       else
         tile_zero<L>(cur);
