@@ -611,8 +611,10 @@ int forward_impl(const AmberMpnDesc* desc, const float* params, const float* pac
 // ---------------------------------------------------------------------------------------------------
 int validate_train(const AmberMpnDesc& d) {
   if (d.has_head) {
-    if (d.decoder_activation > AMBER_ACT_TANH)
-      return fail(AMBER_ERR_UNSUPPORTED, "training: decoder activation id %d (relu, leakyrelu, tanh only)", d.decoder_activation);
+    // the backward expresses act' through the activation's output, which the chain recomputes; silu / mish / gelu would
+    // need the pre-activation
+    if (d.decoder_activation > AMBER_ACT_TANH && d.decoder_activation != AMBER_ACT_ELU)
+      return fail(AMBER_ERR_UNSUPPORTED, "training: decoder activation id %d (relu, leakyrelu, tanh, elu only)", d.decoder_activation);
     if (d.decoder_norm != AMBER_NORM_NONE && d.decoder_norm != AMBER_NORM_LAYER)
       return fail(AMBER_ERR_UNSUPPORTED, "training: decoder BatchNorm is not built (latent_normalization none / layer are)");
   }

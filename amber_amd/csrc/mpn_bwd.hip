@@ -76,7 +76,8 @@ DEVINL void tile_act_w(Tile<L>& t, int act, float* stage, int lane) {
   }
 }
 // d *= act'(pre-activation), expressed through the activation's OUTPUT a (relu / leakyrelu: the sign survives;
-// tanh: 1 - a^2).  At a == 0 torch's backward takes the negative branch (x > 0 ? 1 : slope).
+// tanh: 1 - a^2; elu: a + 1 = exp(x) on the negative side).  At a == 0 torch's backward takes the negative branch
+// (x > 0 ? 1 : slope).
 template <int L>
 DEVINL void tile_mul_dact(Tile<L>& d, const Tile<L>& a, int act) {
   if (act == AMBER_ACT_TANH) {
@@ -84,6 +85,11 @@ DEVINL void tile_mul_dact(Tile<L>& d, const Tile<L>& a, int act) {
     for (int fb = 0; fb < L / 32; ++fb)
 #pragma unroll
       for (int i = 0; i < 16; ++i) d.a[fb][i] *= 1.f - a.a[fb][i] * a.a[fb][i];
+  } else if (act == AMBER_ACT_ELU) {
+#pragma unroll
+    for (int fb = 0; fb < L / 32; ++fb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) d.a[fb][i] = a.a[fb][i] > 0.f ? d.a[fb][i] : d.a[fb][i] * (a.a[fb][i] + 1.f);
   } else {
     const float slope = act == AMBER_ACT_LEAKYRELU ? 0.01f : 0.f;
 #pragma unroll

@@ -453,6 +453,26 @@ def test_decoder_layernorm_gradients_match_oracle(gpu_device, dec_layers, latent
         _check_grads_kink_aware(model, want, flips)
 
 
+@pytest.mark.parametrize("norm", ["none", "layer"])
+def test_decoder_elu_gradients_match_oracle(gpu_device, norm):
+    """A decoder with elu in training (its derivative follows from the output: exp(x) = elu(x) + 1 on the negative side),
+    with and without a LayerNorm behind every layer."""
+    cfg = _cfg(64, 2, dec_layers=3, dec_act="elu")
+    cfg["decoder"]["regularization"]["latent_normalization"] = norm
+    rng = np.random.default_rng(41)
+    el, n, mask = syn.hierarchical_graph(15, 12, 2, 2, rng)
+    g = syn.make_batch([el], [n], 4, 2, seed=6, mask_outputs=[mask])
+    params = orc.init_params(cfg, seed=12)
+    d = dict(x=g.x, edge_attr=g.edge_attr, edge_index=g.edge_index, batch=g.batch, mask_output=g.mask_output)
+    grad_out = torch.randn(int(g.mask_output.sum()), 1, generator=torch.Generator().manual_seed(10))
+    model = _model(cfg, params, d, gpu_device).train()
+    out = model(_batch(d, gpu_device))
+    (out * grad_out.to(gpu_device)).sum().backward()
+    want_out, want, flips = _oracle_grads_with_kinks(cfg, params, g.x, g.edge_attr, g.edge_index, g.mask_output, grad_out)
+    assert close(out.detach().cpu(), want_out.float())
+    _check_grads_kink_aware(model, want, flips)  # the stack's leakyrelu has kinks; elu has none
+
+
 def test_latent_256_gradients_match_oracle(gpu_device):
     """The upper end of north_star's width range trains as well (exact fp32 kernels, like its forward): hub rows longer than a
     tile, zero in-degree nodes, a partial mask."""
@@ -473,7 +493,7 @@ def test_latent_256_gradients_match_oracle(gpu_device):
 
 def test_unsupported_training_configurations_raise(gpu_device):
     """What the backward is not built for raises instead of returning wrong gradients: decoder activations beyond relu /
-    leakyrelu / tanh (their derivative needs the pre-activation, which the tape does not keep)."""
+    leakyrelu / tanh / elu (their derivative needs the pre-activation, which the tape does not keep)."""
     cfg = _cfg(32, 1, dec_act="gelu")
     g = syn.grid_batch(num_graphs=1, nx=5, ny=5)
     d = dict(x=g.x, edge_attr=g.edge_attr, edge_index=g.edge_index, batch=g.batch, mask_output=g.mask_output)
