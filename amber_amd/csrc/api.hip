@@ -611,16 +611,16 @@ int forward_impl(const AmberMpnDesc* desc, const float* params, const float* pac
 // ---------------------------------------------------------------------------------------------------
 int validate_train(const AmberMpnDesc& d) {
   if (d.has_head) {
-    // the backward expresses act' through the activation's output, which the chain recomputes; silu / mish / gelu would
-    // need the pre-activation
-    if (d.decoder_activation > AMBER_ACT_TANH && d.decoder_activation != AMBER_ACT_ELU)
-      return fail(AMBER_ERR_UNSUPPORTED, "training: decoder activation id %d (relu, leakyrelu, tanh, elu only)", d.decoder_activation);
     if (d.decoder_norm != AMBER_NORM_NONE && d.decoder_norm != AMBER_NORM_LAYER)
       return fail(AMBER_ERR_UNSUPPORTED, "training: decoder BatchNorm is not built (latent_normalization none / layer are)");
   }
   return AMBER_OK;
 }
 
+// decoder activations whose derivative the backward takes from the stored pre-activation (the others: from the output)
+bool decoder_needs_pre(const AmberMpnDesc& d) {
+  return d.decoder_activation == AMBER_ACT_SILU || d.decoder_activation == AMBER_ACT_MISH || d.decoder_activation == AMBER_ACT_GELU;
+}
 struct BwdWorkspace {
   float *dX, *dE, *M, *DM, *Ps, *Pd, *dPs, *dPd;
   float* AN[kMaxLayers];
@@ -628,6 +628,7 @@ struct BwdWorkspace {
   float* AE[kMaxLayers];
   float* DHE[kMaxLayers];
   float* APN[kMaxLayers];  // decoder LayerNorm: activations before the norm
+  float* PREN[kMaxLayers];  // decoder silu / mish / gelu: pre-activations (their derivative is not a function of the output)
   float *gpart, *cpart, *lnpart, *pnpart, *epart, *mats;
   size_t mat_floats;
   size_t bytes;
@@ -657,10 +658,12 @@ BwdWorkspace carve_bwd(const AmberMpnDesc& d, int64_t N, int64_t E, void* base) 
   const int ne = d.mlp_layers > d.embed_layers ? d.mlp_layers : d.embed_layers;
   const int nn = ne > d.decoder_layers ? ne : d.decoder_layers;
   const bool dnorm = d.has_head && d.decoder_norm == AMBER_NORM_LAYER;
+  const bool dpre = d.has_head && decoder_needs_pre(d);
   for (int l = 0; l < kMaxLayers; ++l) {
     w.AN[l] = l < nn ? take(nb) : nullptr;
     w.DHN[l] = l < nn ? take(nb) : nullptr;
     w.APN[l] = dnorm && l < d.decoder_layers ? take(nb) : nullptr;
+    w.PREN[l] = dpre && l < d.decoder_layers ? take(nb) : nullptr;
   }
   w.dE = take(eb);
   for (int l = 0; l < kMaxLayers; ++l) {
@@ -745,6 +748,7 @@ int backward_impl(const AmberMpnDesc* desc, const float* params, const float* pa
       }
       a.A[l] = w.AN[l];
       a.DH[l] = w.DHN[l];
+      a.PRE[l] = w.PREN[l];  // nullptr unless the activation needs it
     }
     const bool dnorm = d.decoder_norm == AMBER_NORM_LAYER && nd > 0;
     const int gwaves = gn * kBwdWavesPerBlock;

@@ -98,6 +98,38 @@ DEVINL void tile_mul_dact(Tile<L>& d, const Tile<L>& a, int act) {
       for (int i = 0; i < 16; ++i) d.a[fb][i] = a.a[fb][i] > 0.f ? d.a[fb][i] : slope * d.a[fb][i];
   }
 }
+// act'(x) from the pre-activation x (torch's formulas: silu, mish with softplus threshold 20, exact gelu)
+DEVINL float dact_one(float x, int act) {
+  switch (act) {
+    case AMBER_ACT_SILU: {
+      const float sg = 1.f / (1.f + expf(-x));
+      return sg * (1.f + x * (1.f - sg));
+    }
+    case AMBER_ACT_MISH: {
+      const float sp = x > 20.f ? x : log1pf(expf(x));
+      const float t = tanhf(sp);
+      const float sg = 1.f / (1.f + expf(-x));  // d softplus / dx (1 beyond the threshold to fp32)
+      return t + x * (1.f - t * t) * sg;
+    }
+    case AMBER_ACT_GELU:
+      return 0.5f * (1.f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * expf(-0.5f * x * x);
+    default:
+      return 1.f;
+  }
+}
+// d *= act'(pre) through the wave's LDS stage (one instance of each math routine)
+template <int L>
+DEVINL void tile_mul_dact_pre(Tile<L>& d, const Tile<L>& pre, int act, float* stage, int lane) {
+  wave_sync();
+  tile_stage<L>(stage, pre, lane & 31, lane >> 5);
+  wave_sync();
+  for (int i = lane; i < stage_floats<L>(); i += 64) stage[i] = dact_one(stage[i], act);
+  wave_sync();
+  Tile<L> f;
+  tile_unstage<L>(stage, f, lane & 31, lane >> 5);
+#pragma unroll
+  for (int fb = 0; fb < L / 32; ++fb) d.a[fb] = d.a[fb] * f.a[fb];
+}
 // sum over the L features of this lane's row (the row lives in lanes (0, c) and (1, c))
 template <int L>
 DEVINL float tile_row_sum(const Tile<L>& t) {
@@ -241,11 +273,12 @@ __global__ __launch_bounds__(kBlock, L <= 64 ? 2 : 1) void chain_bwd_kernel(cons
     int64_t p = p0 + c;
     if (p > a.rows - 1) p = a.rows - 1;  // rows beyond the end repeat the last row; their gradient is zeroed below
     const bool rowok = c < nvalid;
-    bool ln_outer = false, has_m = a.mode == AMBER_BWD_NODE, dnorm = false;
+    bool ln_outer = false, has_m = a.mode == AMBER_BWD_NODE, dnorm = false, use_pre = false;
     if constexpr (EXT) {
       ln_outer = a.layer_norm == AMBER_MODE_OUTER;
       has_m = has_m && a.m != nullptr;
       dnorm = a.mode == AMBER_BWD_HEAD && a.pn_gamma[0] != nullptr;
+      use_pre = a.mode == AMBER_BWD_HEAD && a.PRE[0] != nullptr;
     }
     // is the residual term inside the LayerNorm's input?  (outer LayerNorm: whenever there is a residual at all)
     const bool res_in_ln = ln_outer ? a.residual != AMBER_MODE_NONE : a.residual == AMBER_MODE_INNER;
@@ -276,6 +309,9 @@ __global__ __launch_bounds__(kBlock, L <= 64 ? 2 : 1) void chain_bwd_kernel(cons
       }
     }
     if (a.nl > 0) {
+      if constexpr (EXT) {
+        if (use_pre) tile_store_w<L>(stage, cur, a.PRE[0], p0, nvalid, lane);
+      }
       tile_act_w<L>(cur, a.act, stage, lane);
       if constexpr (EXT) {
         if (dnorm) {
@@ -289,6 +325,9 @@ __global__ __launch_bounds__(kBlock, L <= 64 ? 2 : 1) void chain_bwd_kernel(cons
         Tile<L> nxt;
         tile_load_vec<L>(nxt, a.layers[l].b, h);
         GEMM(nxt, a.layers[l].w, cur, lane);
+        if constexpr (EXT) {
+          if (use_pre) tile_store_w<L>(stage, nxt, a.PRE[l], p0, nvalid, lane);
+        }
         tile_act_w<L>(nxt, a.act, stage, lane);
         cur = nxt;
         if constexpr (EXT) {
@@ -382,7 +421,7 @@ __global__ __launch_bounds__(kBlock, L <= 64 ? 2 : 1) void chain_bwd_kernel(cons
           tile_store_w<L>(stage, dr, a.dio, p0, nvalid, lane);
       }
       // rows stored above are re-read by other lanes of this wave
-      if (a.nl > 1 || dnorm || (res_any && !(PARK && keep))) wave_global_handover();
+      if (a.nl > 1 || dnorm || use_pre || (res_any && !(PARK && keep))) wave_global_handover();
       // decoder LayerNorm behind layer l: dr arrives at n_l = LN_l(a_l) and leaves at a_l
       auto post_norm_bwd = [&](int l) {
         if constexpr (EXT) {
@@ -426,7 +465,15 @@ __global__ __launch_bounds__(kBlock, L <= 64 ? 2 : 1) void chain_bwd_kernel(cons
           post_norm_bwd(l);
         else if (l != a.nl - 1)
           tile_load_row<L>(cur, a.A[l], p, h);
-        tile_mul_dact<L>(dr, cur, a.act);
+        bool from_pre = false;
+        if constexpr (EXT) {
+          if (use_pre) {
+            tile_load_row<L>(cur, a.PRE[l], p, h);
+            tile_mul_dact_pre<L>(dr, cur, a.act, stage, lane);
+            from_pre = true;
+          }
+        }
+        if (!from_pre) tile_mul_dact<L>(dr, cur, a.act);
         tile_store_w<L>(stage, dr, a.DH[l], p0, nvalid, lane);
         Tile<L> nd;
         tile_zero<L>(nd);
@@ -437,7 +484,17 @@ __global__ __launch_bounds__(kBlock, L <= 64 ? 2 : 1) void chain_bwd_kernel(cons
         post_norm_bwd(0);
       else if (a.nl > 1)
         tile_load_row<L>(cur, a.A[0], p, h);
-      tile_mul_dact<L>(dr, cur, a.act);
+      {
+        bool from_pre = false;
+        if constexpr (EXT) {
+          if (use_pre) {
+            tile_load_row<L>(cur, a.PRE[0], p, h);
+            tile_mul_dact_pre<L>(dr, cur, a.act, stage, lane);
+            from_pre = true;
+          }
+        }
+        if (!from_pre) tile_mul_dact<L>(dr, cur, a.act);
+      }
       tile_store_w<L>(stage, dr, a.DH[0], p0, nvalid, lane);
       if (has_m) {
         tile_zero<L>(cur);
@@ -1332,7 +1389,8 @@ template <int L>
 static hipError_t launch_chain_bwd_t(const ChainBwdArgs& a, hipStream_t s) {
   const int64_t ntiles = cdiv(a.rows, kTile);
   const bool ext = a.residual == AMBER_MODE_OUTER || a.layer_norm == AMBER_MODE_OUTER ||
-                   (a.mode == AMBER_BWD_NODE && a.m == nullptr) || (a.mode == AMBER_BWD_HEAD && a.pn_gamma[0] != nullptr);
+                   (a.mode == AMBER_BWD_NODE && a.m == nullptr) ||
+                   (a.mode == AMBER_BWD_HEAD && (a.pn_gamma[0] != nullptr || a.PRE[0] != nullptr));
   const dim3 grid(chain_bwd_grid(a.rows));
   if constexpr (L <= 128) {
     if (a.split) {

@@ -206,6 +206,8 @@ struct ChainBwdArgs {
   const float* pn_gamma[kMaxLayers];
   const float* pn_beta[kMaxLayers];
   float* AP[kMaxLayers];  // [rows,L] activation of layer l before its LayerNorm
+  // head with an activation whose derivative needs the pre-activation (silu, mish, gelu): [rows,L] W_l in_l + b_l, else nullptr
+  float* PRE[kMaxLayers];
   float* pn_part;         // [grid waves][nl][2][L] (d gamma_l, d beta_l) sums, zeroed by the caller
   float* dio;             // [rows,L] in: gradient at the module's output; out: gradient at rin (head: added to)
   const float* dm_in;     // edge: [N,L] gradient at the mean aggregate (divided by the in-degree here)

@@ -227,9 +227,9 @@ int amber_mpn_forward_timed(const AmberMpnDesc* desc, const float* params, const
  * Arithmetic of the backward's contractions: exact fp32 MFMA for AMBER_PREC_FP32 and at latent 256 (correct and slow there);
  * otherwise every float as three bf16 pieces on the fp16-rate pipe (six piece products, relative error <= 2^-22).
  * Built for: every latent width of the forward; residual / layer_norm none, inner or outer (message_passing_block.py:62-74,91-97);
- * constant, linear or LatentMLP embeddings (embedding.py:32-38); decoder activations relu / leakyrelu / tanh / elu with
- * latent_normalization none or layer (mlp.py:86-93).  Decoder BatchNorm and the other decoder activations return
- * AMBER_ERR_UNSUPPORTED.
+ * constant, linear or LatentMLP embeddings (embedding.py:32-38); every decoder activation of the forward (silu / mish /
+ * gelu: the head's chain keeps their pre-activations in the workspace) with latent_normalization none or layer
+ * (mlp.py:86-93).  Decoder BatchNorm returns AMBER_ERR_UNSUPPORTED.
  * ------------------------------------------------------------------------------------------------- */
 size_t amber_mpn_tape_bytes(const AmberMpnDesc* desc, int64_t num_nodes, int64_t num_edges);
 int amber_mpn_forward_train(const AmberMpnDesc* desc, const float* params, const float* packed, int64_t num_nodes,

@@ -112,7 +112,7 @@ CASES = {
 # cases inside what amber_mpn_backward is built for (include/amber_mpn.h)
 TRAINABLE = ("debug_L64_s2", "synth_L128_s2", "hier_L64_s3", "none_tanh_L32", "const_edge_L32", "const_node_L32", "repeat_L32_l3",
              "specnorm_L32", "outer_relu_L32", "mix_io_L32", "mix_oi_L32", "embmlp_L32", "decnorm_lrelu_L32", "embmlp3_tanh_L64",
-             "outer_hier_L64", "L256_s2")
+             "outer_hier_L64", "L256_s2", "decnorm_L32", "onelayer_L64")
 
 
 def main():

@@ -454,10 +454,12 @@ def test_decoder_layernorm_gradients_match_oracle(gpu_device, dec_layers, latent
 
 
 @pytest.mark.parametrize("norm", ["none", "layer"])
-def test_decoder_elu_gradients_match_oracle(gpu_device, norm):
-    """A decoder with elu in training (its derivative follows from the output: exp(x) = elu(x) + 1 on the negative side),
-    with and without a LayerNorm behind every layer."""
-    cfg = _cfg(64, 2, dec_layers=3, dec_act="elu")
+@pytest.mark.parametrize("dec_act", ["elu", "silu", "gelu", "mish"])
+def test_decoder_smooth_activations_gradients_match_oracle(gpu_device, dec_act, norm):
+    """Decoders with elu (derivative from the output: exp(x) = elu(x) + 1 on the negative side) and with silu / gelu / mish
+    (derivative from the pre-activation, which the head's chain keeps for them) in training, with and without a LayerNorm
+    behind every layer (mlp.py:60-95)."""
+    cfg = _cfg(64, 2, dec_layers=3, dec_act=dec_act)
     cfg["decoder"]["regularization"]["latent_normalization"] = norm
     rng = np.random.default_rng(41)
     el, n, mask = syn.hierarchical_graph(15, 12, 2, 2, rng)
@@ -470,7 +472,7 @@ def test_decoder_elu_gradients_match_oracle(gpu_device, norm):
     (out * grad_out.to(gpu_device)).sum().backward()
     want_out, want, flips = _oracle_grads_with_kinks(cfg, params, g.x, g.edge_attr, g.edge_index, g.mask_output, grad_out)
     assert close(out.detach().cpu(), want_out.float())
-    _check_grads_kink_aware(model, want, flips)  # the stack's leakyrelu has kinks; elu has none
+    _check_grads_kink_aware(model, want, flips)  # the stack's leakyrelu has kinks; the decoder's activation has none
 
 
 def test_latent_256_gradients_match_oracle(gpu_device):
@@ -492,13 +494,14 @@ def test_latent_256_gradients_match_oracle(gpu_device):
 
 
 def test_unsupported_training_configurations_raise(gpu_device):
-    """What the backward is not built for raises instead of returning wrong gradients: decoder activations beyond relu /
-    leakyrelu / tanh / elu (their derivative needs the pre-activation, which the tape does not keep)."""
-    cfg = _cfg(32, 1, dec_act="gelu")
+    """What the backward is not built for raises instead of returning wrong gradients: a decoder with BatchNorm (batch
+    statistics and running-buffer updates, mlp.py:86-93)."""
+    cfg = _cfg(32, 1)
+    cfg["decoder"]["regularization"]["latent_normalization"] = "batch"
     g = syn.grid_batch(num_graphs=1, nx=5, ny=5)
     d = dict(x=g.x, edge_attr=g.edge_attr, edge_index=g.edge_index, batch=g.batch, mask_output=g.mask_output)
     model = _model(cfg, orc.init_params(cfg, seed=2), d, gpu_device).train()
-    with pytest.raises(RuntimeError, match="decoder activation"):
+    with pytest.raises(NotImplementedError, match="BatchNorm"):
         model(_batch(d, gpu_device))
     with torch.no_grad():  # inference of the same model is fine
         model.eval()(_batch(d, gpu_device))
