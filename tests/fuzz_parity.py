@@ -90,14 +90,15 @@ def main():
     t0 = time.time()
     for case in range(args.cases):
         cfg = random_cfg(rng)
-        if args.grads:  # what the training path supports (supervised_mpn.py: no decoder normalisation), smooth
+        if args.grads:  # what the training path supports (everything but decoder BatchNorm), smooth activations only
             cfg["stack"]["mlp"]["activation_function"] = "tanh"
-            cfg["decoder"]["activation_function"] = "tanh"
-            cfg["decoder"]["regularization"]["latent_normalization"] = None
+            if cfg["decoder"]["activation_function"] in ("relu", "leakyrelu"):
+                cfg["decoder"]["activation_function"] = "tanh"
+            if cfg["decoder"]["regularization"]["latent_normalization"] == "batch":
+                cfg["decoder"]["regularization"]["latent_normalization"] = "layer"
             cfg["edge_dropout"] = 0.0
-            for k in ("residual_connections", "layer_norm"):  # 'outer' is not built for training
-                cfg["stack"][k] = "inner" if cfg["stack"][k] == "outer" else cfg["stack"][k]
-            cfg["embedding"] = None  # MLP input embeddings are not built for training
+            if cfg["embedding"] is not None:
+                cfg["embedding"]["mlp"]["activation_function"] = "tanh"
         fn, fe = int(rng.choice([0, 1, 3, 4, 7, 12])), int(rng.choice([0, 1, 2, 5, 9]))
         g, kind = random_batch(rng, fn, fe)
         torch.manual_seed(int(rng.integers(1 << 30)))
@@ -138,7 +139,8 @@ def main():
                     v.is_floating_point() and not k.endswith(("weight_u", "weight_v"))) for k, v in params.items()}
                 o = orc.supervised_mpn_forward(p, ocfg, g.x.to(dt), g.edge_attr.to(dt), g.edge_index, g.mask_output)
                 (o * grad_out.to(dt)).sum().backward()
-                return {k: v.grad for k, v in p.items() if v.grad is not None}
+                # None: the output does not depend on the parameter (outer LayerNorm of the last block's edges) = zero
+                return {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in p.items() if v.requires_grad}
 
             g32, g64 = oracle_grads(sd, torch.float32), oracle_grads(sd, torch.float64)
             gnoise = max(rel_err(g32[k].double(), g64[k]) for k in g32)
