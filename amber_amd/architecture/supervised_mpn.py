@@ -73,11 +73,33 @@ class SupervisedMPN(nn.Module):
         self._mask_cache = (weakref.ref(mask), mask._version, out_index, n_out)
         return out_index, n_out
 
-    def _check_train_mode_decoder(self):
+    def _decoder_runs_as_modules(self) -> bool:
         """In train() mode the reference's decoder applies dropout and BatchNorm batch statistics (and updates the running
-        buffers) whatever the autograd mode (mlp.py:128-129).  The kernels implement the eval-mode forms only, so those
-        configurations raise in train() mode - also under torch.no_grad() or with frozen parameters - instead of
-        returning eval-mode numbers."""
+        buffers) whatever the autograd mode (mlp.py:128-129); the fused head implements the eval-mode forms only.  For
+        those configurations - off AMBER's defaults (config/algorithm/architecture/decoder/mlp.yaml: dropout 0, no latent
+        normalisation) - the message-passing stack runs through the HIP kernels and the decoder's own torch modules are
+        applied to its latents (N_masked x L rows: torch's dropout generator, batch statistics and buffer updates are then
+        the reference's by construction).  The same for BatchNorm in eval mode with gradients asked for (its backward is not
+        in the C library)."""
+        mods = list(self.decoder_mlp.mlp_layers)
+        has_bn = any(isinstance(m, nn.BatchNorm1d) for m in mods)
+        if self.training:
+            return has_bn or any(isinstance(m, nn.Dropout) and m.p > 0 for m in mods)
+        return has_bn and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+
+    def _forward_module_decoder(self, observations) -> torch.Tensor:
+        """supervised_mpn.py:48-54 with the stack on the HIP path (autograd through amber_mpn_backward for the latents)."""
+        node_features, _, _ = self.mpn(observations)
+        node_features = node_features.get(self._node_type)
+        if hasattr(observations, "mask_output"):
+            node_features = node_features[observations.mask_output]
+        for layer in self.decoder_mlp.mlp_layers:
+            node_features = layer(node_features)
+        return self.readout(node_features)
+
+    def _check_train_mode_decoder(self):
+        """fused_predict is an inference call: in train() mode a decoder with dropout or BatchNorm would silently get
+        eval-mode numbers there, so it raises (forward() handles those configurations, see _decoder_runs_as_modules)."""
         if not self.training:
             return
         for m in self.decoder_mlp.mlp_layers:
@@ -90,15 +112,14 @@ class SupervisedMPN(nn.Module):
     def forward(self, observations, **kwargs) -> torch.Tensor:
         """observations: (batch of) observation graph(s) on the GPU.  Returns one scalar per kept node,
         shape [N_masked, 1] (all nodes when the batch has no `mask_output`)."""
-        self._check_train_mode_decoder()
+        if self._decoder_runs_as_modules():
+            return self._forward_module_decoder(observations)
         observations, csr = self.mpn.prepare(observations)
         n = csr.num_nodes
         out_index, n_out = self._out_index(observations, n)
         dec = self.decoder_mlp
         desc, base, dec_pieces, dec_sources, tail = self._plan(single_row=(n_out == 1))
         if engine.wants_grad(base + dec_sources + tail):  # training step (src/algorithm/core/amber.py:62-82)
-            if dec.latent_normalization == "batch":
-                raise NotImplementedError("amber_amd: decoder BatchNorm is not built for training (latent_normalization none / layer are)")
             return engine.MpnFunction.apply(desc, self._packed, observations.x, observations.edge_attr, csr, out_index, n_out,
                                             False, False, base + dec_sources + tail, *(base + dec_pieces + tail))[2]
         flat, packed = self._packed.get(desc, base + dec_pieces + tail, key_tensors=base + dec_sources + tail

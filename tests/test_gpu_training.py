@@ -493,15 +493,72 @@ def test_latent_256_gradients_match_oracle(gpu_device):
     _check_grads(model, want, GRAD_TOL)
 
 
-def test_unsupported_training_configurations_raise(gpu_device):
-    """What the backward is not built for raises instead of returning wrong gradients: a decoder with BatchNorm (batch
-    statistics and running-buffer updates, mlp.py:86-93)."""
-    cfg = _cfg(32, 1)
+def test_train_mode_batchnorm_decoder_runs_as_modules_on_the_hip_latents(gpu_device):
+    """Decoder BatchNorm in train() mode (off AMBER's defaults): the stack runs through the HIP kernels, the decoder's own
+    torch modules are applied to its latents - batch statistics over the kept nodes, running buffers updated
+    (mlp.py:86-93, supervised_mpn.py:48-54).  Checked against the float64 oracle stack followed by float64 copies of the
+    same modules: output, the buffers' update and every parameter gradient."""
+    import copy
+
+    cfg = _cfg(32, 2, act="tanh", dec_layers=2, dec_act="tanh")
     cfg["decoder"]["regularization"]["latent_normalization"] = "batch"
-    g = syn.grid_batch(num_graphs=1, nx=5, ny=5)
+    rng = np.random.default_rng(51)
+    el, n, mask = syn.hierarchical_graph(14, 11, 2, 2, rng)
+    g = syn.make_batch([el], [n], 4, 2, seed=7, mask_outputs=[mask])
     d = dict(x=g.x, edge_attr=g.edge_attr, edge_index=g.edge_index, batch=g.batch, mask_output=g.mask_output)
-    model = _model(cfg, orc.init_params(cfg, seed=2), d, gpu_device).train()
-    with pytest.raises(NotImplementedError, match="BatchNorm"):
-        model(_batch(d, gpu_device))
-    with torch.no_grad():  # inference of the same model is fine
+    params = orc.init_params(cfg, seed=4)
+    model = _model(cfg, params, d, gpu_device).train()
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    ref_dec = copy.deepcopy(model.decoder_mlp.mlp_layers).cpu().double().train()
+    ref_readout = copy.deepcopy(model.readout).cpu().double()
+    grad_out = torch.randn(int(g.mask_output.sum()), 1, generator=torch.Generator().manual_seed(3))
+    out = model(_batch(d, gpu_device))
+    (out * grad_out.to(gpu_device)).sum().backward()
+    # float64 reference: oracle stack (differentiable in its parameters) + the same modules
+    p64 = {k: (v.double().requires_grad_(True) if v.is_floating_point() and k.startswith("mpn.") else v) for k, v in sd.items()}
+    xl, _ = orc.mpn_forward(p64, cfg, g.x.double(), g.edge_attr.double(), g.edge_index, prefix="mpn.")
+    t = xl[g.mask_output]
+    for layer in ref_dec:
+        t = layer(t)
+    want = ref_readout(t)
+    (want * grad_out.double()).sum().backward()
+    assert close(out.detach().cpu(), want.detach().float())
+    bn, bn64 = model.decoder_mlp.mlp_layers[2], ref_dec[2]
+    assert not torch.equal(bn.running_mean.cpu(), sd["decoder_mlp.mlp_layers.2.running_mean"])  # updated
+    assert close(bn.running_mean.cpu(), bn64.running_mean.float()) and close(bn.running_var.cpu(), bn64.running_var.float())
+    got = {k: p.grad.detach().cpu() for k, p in model.named_parameters()}
+    for k, p in p64.items():
+        if k.startswith("mpn.") and torch.is_tensor(p) and p.requires_grad:
+            w = p.grad if p.grad is not None else torch.zeros_like(p)
+            scale = max(float(w.abs().max()), 1e-30)
+            assert float((got[k].double() - w).abs().max()) <= GRAD_TOL * scale, k
+    for (k, p), q in zip(list(model.decoder_mlp.mlp_layers.named_parameters()) + list(model.readout.named_parameters()),
+                         list(ref_dec.parameters()) + list(ref_readout.parameters())):
+        scale = max(float(q.grad.abs().max()), 1e-30)
+        assert float((p.grad.detach().cpu().double() - q.grad).abs().max()) <= GRAD_TOL * scale, k
+    with torch.no_grad():  # inference of the same model: the fused head with the (updated) running statistics folded in
         model.eval()(_batch(d, gpu_device))
+
+
+def test_train_mode_decoder_dropout_uses_torch_generator(gpu_device):
+    """Decoder dropout in train() mode: torch's own modules on the HIP latents, so the masks come from the device generator
+    exactly as in the reference - the same seed gives the same output, and it equals the modules applied by hand."""
+    cfg = _cfg(32, 1, act="tanh", dec_layers=2, dec_act="tanh")
+    cfg["decoder"]["regularization"]["dropout"] = 0.5
+    g = syn.grid_batch(num_graphs=2, nx=6, ny=5)
+    d = dict(x=g.x, edge_attr=g.edge_attr, edge_index=g.edge_index, batch=g.batch, mask_output=g.mask_output)
+    model = _model(cfg, orc.init_params(cfg, seed=6), d, gpu_device).train()
+    torch.manual_seed(123)
+    out1 = model(_batch(d, gpu_device)).detach()
+    torch.manual_seed(123)
+    out2 = model(_batch(d, gpu_device)).detach()
+    assert torch.equal(out1, out2)
+    with torch.no_grad():
+        lat = model.mpn(_batch(d, gpu_device))[0]["node"][g.mask_output.to(gpu_device)]
+        torch.manual_seed(123)
+        t = lat
+        for layer in model.decoder_mlp.mlp_layers:
+            t = layer(t)
+        by_hand = model.readout(t)
+        assert torch.equal(by_hand, out1)
+        assert not torch.equal(model.eval()(_batch(d, gpu_device)), out1)  # eval: dropout is the identity

@@ -67,22 +67,32 @@ def test_decoder_batchnorm_folding_and_module_indices():
     assert len(sources) == 2 * (2 + 4)
 
 
-def test_train_mode_decoder_regularisation_raises_whatever_the_grad_mode():
+def test_train_mode_decoder_regularisation_never_gets_eval_mode_numbers():
     """train() + no_grad (or frozen parameters) must not silently return eval-mode numbers for a decoder with
-    dropout / BatchNorm - the reference applies them in that state (mlp.py:128-129)."""
+    dropout / BatchNorm - the reference applies them in that state (mlp.py:128-129).  forward() then runs the decoder's own
+    torch modules on the stack's latents, whatever the grad mode; the inference-only fused_predict raises."""
     g = syn.grid_batch(num_graphs=1, nx=4, ny=4, in_node_features=3, in_edge_features=2)
     for reg, msg in (({"dropout": 0.5}, "dropout"), ({"latent_normalization": "batch"}, "BatchNorm")):
         cfg = default_architecture(latent_dimension=32, num_steps=1)
         cfg["decoder"]["regularization"].update(reg)
         model = SupervisedMPN(cfg, g).train()
-        with torch.no_grad(), pytest.raises(NotImplementedError, match=msg):
-            model(g)
+        assert model._decoder_runs_as_modules()
+        with torch.no_grad():
+            assert model._decoder_runs_as_modules()
+        with pytest.raises(NotImplementedError, match=msg):
+            model.fused_predict(g, None, None, None, None, None)
         for p in model.parameters():
             p.requires_grad_(False)
-        with pytest.raises(NotImplementedError, match=msg):
+        assert model._decoder_runs_as_modules()
+        with pytest.raises(RuntimeError, match="no CPU path"):  # the stack has no CPU path, in train mode as in eval mode
             model(g)
-        with pytest.raises(RuntimeError, match="no CPU path"):  # eval mode gets past the check (and then needs the GPU)
-            model.eval()(g)
+        model.eval()
+        assert not model._decoder_runs_as_modules()  # inference: the fused head (BatchNorm folded, dropout the identity)
+        for p in model.parameters():
+            p.requires_grad_(True)
+        assert model._decoder_runs_as_modules() == (msg == "BatchNorm")  # eval + autograd: BatchNorm's backward is torch's
+        with pytest.raises(RuntimeError, match="no CPU path"):
+            model(g)
 
 
 def test_plan_cache_is_dropped_when_parameters_are_recreated():
