@@ -244,7 +244,12 @@ def train_bench(args):
                                    f"grids per GPU, N={n} E={e}, latent {args.latent}, {args.mp_steps} MP steps, edge_dropout {cfg['edge_dropout']} "
                                    f"with a fresh CSR per step for the kept edges (BASELINE config 3 shape by default)",
                        "parallelism": f"graph-wise dp{world}, one gradient all-reduce per step",
-                       "backend": dist.get_backend() if dist is not None else None}}), flush=True)
+                       "backend": dist.get_backend() if dist is not None else None,
+                       "backward": ("exact fp32 MFMA" if engine.default_precision == "fp32" or args.latent == 256
+                                    or os.environ.get("AMBER_MPN_EXACT_BACKWARD") else
+                                    "bf16x3 operands" + (", chain and weight gradients of a module fused"
+                                                         if args.latent <= 64 and not os.environ.get("AMBER_MPN_NO_FUSED_BACKWARD")
+                                                         else ""))}}), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 
