@@ -87,11 +87,14 @@ int validate(const AmberMpnDesc* d) {
 
 bool use_fast_head(const AmberMpnDesc& d);
 bool use_node_fold(const AmberMpnDesc& d);
+bool use_b3_forward(const AmberMpnDesc& d);
 
 Layout build_layout(const AmberMpnDesc& d) {
   Layout lay;
   const int64_t L = d.latent;
   int64_t po = 0, pk = 0;
+  // one packed matrix: L*L floats (exact fp32 tiles, hi/lo fp16 pairs) or 3 L*L bf16 pieces, + header
+  const int64_t mat_floats = (use_b3_forward(d) ? L * L * 3 / 2 : L * L) + kPackedHeader;
   auto mlp = [&](MlpLayout& m, int layers, int in_cols, int col_blocks, bool norm, bool pack_first) {
     m.layers = layers;
     m.in_cols = in_cols;
@@ -115,11 +118,11 @@ Layout build_layout(const AmberMpnDesc& d) {
         if (pack_first)
           for (int cb = 0; cb < col_blocks; ++cb) {
             m.PW[0][cb] = pk;
-            pk += L * L + kPackedHeader;
+            pk += mat_floats;
           }
       } else {
         m.PW[l][0] = pk;
-        pk += L * L + kPackedHeader;
+        pk += mat_floats;
       }
     }
   };
@@ -305,6 +308,8 @@ int dbg_switches() {
 bool use_split_backward(const AmberMpnDesc& d) {
   return d.precision != AMBER_PREC_FP32 && bwd_split_supported(d.latent) && !env_switches().exact_backward;
 }
+// latent 256 outside the exact mode: the row-per-lane kernels on bf16x3 operands (every packed matrix in that format)
+bool use_b3_forward(const AmberMpnDesc& d) { return d.precision != AMBER_PREC_FP32 && fwd_b3_supported(d.latent); }
 bool use_fast_edge(const AmberMpnDesc& d) {
   return d.precision != AMBER_PREC_FP32 && edge_f2_supported(d.latent, d.mlp_layers, d.activation, d.residual, d.layer_norm);
 }
@@ -340,13 +345,13 @@ hipError_t run_edge(const AmberMpnDesc& d, EdgeArgs& ea, hipStream_t s) {
     return launch_edge_f2(d.latent, ea, device_cus(), s);
   }
   ea.red_shift = 5;
-  return launch_edge(d.latent, ea, s);
+  return launch_edge(d.latent, use_b3_forward(d) ? 1 : 0, ea, s);
 }
 
 // Node launch: the split-precision kernel does the update and the projections; a decoder / readout that rides on the
 // same launch (the exact dense chain) follows as a launch of its own on the updated rows.
 hipError_t run_node(const AmberMpnDesc& d, const NodeArgs& na, hipStream_t s) {
-  if (!na.fast) return launch_node(d.latent, na, s);
+  if (!na.fast) return launch_node(d.latent, use_b3_forward(d) ? 1 : 0, na, s);
   NodeArgs u = na;
   u.dbg = dbg_switches();
   u.single = d.precision == AMBER_PREC_F16 ? 1 : 0;
@@ -365,7 +370,7 @@ hipError_t run_node(const AmberMpnDesc& d, const NodeArgs& na, hipStream_t s) {
   hd.do_proj = 0;
   hd.x_in = na.do_update ? na.x_out : na.x_in;
   hd.x_out = nullptr;
-  return launch_node(d.latent, hd, s);
+  return launch_node(d.latent, use_b3_forward(d) ? 1 : 0, hd, s);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -452,7 +457,7 @@ int run_embedding(const AmberMpnDesc& d, const MlpLayout& m, int F, const float*
     for (int l = 1; l < d.embed_layers; ++l) a.dense[l - 1] = DenseLayer{packed + m.PW[l][0], params + m.B[l], nullptr, nullptr};
     a.dense_out = out;  // in place: a wave reads its 32 rows before it writes them
     tm.begin(AMBER_KC_EMBED);
-    e = launch_node(L, a, s);
+    e = launch_node(L, use_b3_forward(d) ? 1 : 0, a, s);
     tm.end();
     HIP_TRY(e, "embedding MLP kernel");
   }
@@ -517,7 +522,7 @@ int forward_impl(const AmberMpnDesc* desc, const float* params, const float* pac
     }
     if (out_node || want_head) {
       tm.begin(AMBER_KC_NODE);
-      hipError_t e = launch_node(L, a, s);
+      hipError_t e = launch_node(L, use_b3_forward(d) ? 1 : 0, a, s);
       tm.end();
       HIP_TRY(e, "node kernel");
     }
@@ -1036,7 +1041,9 @@ int amber_mpn_pack_weights(const AmberMpnDesc* desc, const float* params, float*
   // chain: exact kernels, decoder); FMT_F2 = hi/lo fp16 as the B operand of the feature-per-lane chain (split-precision
   // edge and node kernels).  `f0[cb]` is the format of column block cb of layer 0, `share0` makes its FMT_F2 blocks
   // share one power-of-two scale (they feed one accumulator), `frest` is the format of layers >= 1.
+  // At latent 256 outside the exact mode the FMT_F32 matrices are bf16x3 pieces instead (use_b3_forward).
   enum { FMT_F32 = 0, FMT_F2 = 2 };
+  const bool b3fwd = use_b3_forward(*desc);
   // the matrices are queued and re-tiled in batched launches (a training step packs ~150 matrices after every
   // optimizer step: one launch each would be ~450 tiny kernels)
   F2PackBatch q2{};
@@ -1055,7 +1062,7 @@ int amber_mpn_pack_weights(const AmberMpnDesc* desc, const float* params, float*
       q2.job[q2.n++] = F2PackJob{W, out, ld, col0, scol0, scols, kperm};
       if (q2.n == kF2PackMaxJobs) return flush();
     } else {
-      q32.job[q32.n++] = PackJob{W, out, ld, col0, 0, AMBER_PACK_F32};
+      q32.job[q32.n++] = PackJob{W, out, ld, col0, 0, b3fwd ? AMBER_PACK_B3 : AMBER_PACK_F32};
       if (q32.n == kPackMaxJobs) return flush();
     }
     return hipSuccess;
@@ -1278,7 +1285,7 @@ int amber_mpn_head(const AmberMpnDesc* desc, const float* params, const float* p
   a.N = num_nodes;
   a.x_in = x_latent;
   fill_node_head(a, *desc, lay, params, packed, out_index, out_sizing);
-  HIP_TRY(launch_node(desc->latent, a, static_cast<hipStream_t>(stream)), "head kernel");
+  HIP_TRY(launch_node(desc->latent, use_b3_forward(*desc) ? 1 : 0, a, static_cast<hipStream_t>(stream)), "head kernel");
   return AMBER_OK;
 }
 

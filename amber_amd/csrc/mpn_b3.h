@@ -1,4 +1,5 @@
-// bf16x3 operands for the fp16-rate matrix pipe (the backward kernels, mpn_bwd.hip).
+// bf16x3 operands for the fp16-rate matrix pipe (the backward kernels, mpn_bwd.hip, and the row-per-lane forward kernels at
+// latent 256, mpn_kernels.hip).
 #pragma once
 #include "mpn_tile.h"
 
@@ -123,6 +124,48 @@ DEVINL void tile_gemm_b3_shared(Tile<L>& acc, const float* __restrict__ wpacked,
       for (int k = 0; k < PER; ++k) wbuf[((s + 1) & 1) * STEP + k * kBlock + tid] = r[k];
     }
     __syncthreads();  // window (s + 1) & 1 is complete, and window s & 1 has been read by every wave
+  }
+}
+
+// The same with ONE window (latent 256: a k-step's pieces are 24 KB and the row stages already take 133 KB of the LDS): the
+// window is refilled between two barriers, the next k-step's pieces are in flight in registers meanwhile.
+template <int L>
+DEVINL void tile_gemm_b3_window(Tile<L>& acc, const float* __restrict__ wpacked, const Tile<L>& in, int lane, u32x4* wwin) {
+  constexpr int NFB = L / 32, NS = L / 16, STEP = NFB * 3 * 64, PER = STEP / kBlock, GF = 2;
+  static_assert(STEP % kBlock == 0 && NFB % GF == 0, "a k-step's pieces divide over the workgroup's threads");
+  const u32x4* __restrict__ wg = reinterpret_cast<const u32x4*>(wpacked);
+  const int tid = (static_cast<int>(threadIdx.x) & ~63) | lane;
+  u32x4 r[PER];
+#pragma unroll
+  for (int k = 0; k < PER; ++k) r[k] = wg[k * kBlock + tid];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    __syncthreads();  // every wave has read the previous k-step's window
+#pragma unroll
+    for (int k = 0; k < PER; ++k) wwin[k * kBlock + tid] = r[k];
+    __syncthreads();
+    if (s + 1 < NS) {
+#pragma unroll
+      for (int k = 0; k < PER; ++k) r[k] = wg[(s + 1) * STEP + k * kBlock + tid];
+    }
+    float v[8];
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) v[jj] = in.a[s >> 1][8 * (s & 1) + jj];
+    u32x4 x[3];
+    split3(v, x);
+    const u32x4* wl = wwin + lane;
+#pragma unroll
+    for (int g = 0; g < NFB; g += GF) {
+      u32x4 wf[GF][3];
+#pragma unroll
+      for (int fb = 0; fb < GF; ++fb)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) wf[fb][q] = wl[((g + fb) * 3 + q) * 64];
+#pragma unroll
+      for (int q = 0; q < 6; ++q)
+#pragma unroll
+        for (int fb = 0; fb < GF; ++fb) acc.a[g + fb] = mfma_b(wf[fb][kB3W[q]], x[kB3X[q]], acc.a[g + fb]);
+    }
   }
 }
 

@@ -125,8 +125,11 @@ struct NodeArgs {
   int32_t single;         // AMBER_PREC_F16, as in EdgeArgs
 };
 
-hipError_t launch_edge(int L, const EdgeArgs& a, hipStream_t s);
-hipError_t launch_node(int L, const NodeArgs& a, hipStream_t s);
+// b3 = 1: the packed matrices are bf16x3 pieces (AMBER_PACK_B3) and the contractions run on the fp16-rate pipe; built for
+// the latent the split-precision feature-per-lane kernels do not take (256)
+constexpr bool fwd_b3_supported(int L) { return L == 256; }
+hipError_t launch_edge(int L, int b3, const EdgeArgs& a, hipStream_t s);
+hipError_t launch_node(int L, int b3, const NodeArgs& a, hipStream_t s);
 // out[r] = act(W in[idx(r)] + b): small-K linear (K = F >= 0), idx = perm gather or identity
 hipError_t launch_embed(int L, const float* in, int64_t rows, int F, const float* W, const float* b, const int32_t* perm,
                         int act_or_neg1, float* out, hipStream_t s);

@@ -21,6 +21,7 @@
 // Aggregation (scatter_mean) is fused into the edge kernel: the tile is staged in LDS and summed
 // sequentially per destination row in CSR order (deterministic, no atomics).  Rows cut by a tile
 // boundary leave partial sums in head/tail buffers that the node kernel adds in tile order.
+#include "mpn_b3.h"
 #include "mpn_post.h"
 #include "mpn_tile.h"
 
@@ -32,9 +33,23 @@ namespace amber {
 //            MessagePassingBlock.forward (src/mpn/message_passing_block.py:117-121,127-128),
 //            scatter_mean call (message_passing_modules.py:68)
 // ---------------------------------------------------------------------------------------------------
-template <int L>
+// B3 (latent 256 outside the exact mode): the matrices arrive as bf16x3 pieces (mpn_b3.h), every contraction runs on the
+// fp16-rate pipe and streams its matrix ONCE per workgroup through an LDS window (tile_gemm_b3_window) - the split-precision
+// form of these kernels where one hi/lo fp16 matrix no longer fits the LDS of the feature-per-lane kernels.  Its barriers
+// need every wave of the workgroup at every contraction: these kernels keep all their waves to the end (rows past the end
+// are clamped) and every contraction sits in workgroup-uniform control flow.
+#define AMBER_GEMM(ACC, W, IN, LANE)                      \
+  do {                                                    \
+    if constexpr (B3)                                     \
+      tile_gemm_b3_window<L>(ACC, W, IN, LANE, wwin);     \
+    else                                                  \
+      tile_gemm<L>(ACC, W, IN, LANE);                     \
+  } while (0)
+
+template <int L, bool B3>
 __global__ __launch_bounds__(kBlock) void edge_kernel(const EdgeArgs a, const int64_t nblk) {
   __shared__ __attribute__((aligned(16))) float stage_all[kWavesPerBlock * stage_floats<L>()];
+  __shared__ __attribute__((aligned(16))) u32x4 wwin[B3 ? (L / 32) * 3 * 64 : 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 31, h = lane >> 5;
   float* stage = stage_all + wave * stage_floats<L>();
@@ -52,13 +67,13 @@ __global__ __launch_bounds__(kBlock) void edge_kernel(const EdgeArgs a, const in
   Tile<L> acc;
   tile_load_row<L>(acc, a.Ps, s, h);
   tile_add_row<L>(acc, a.Pd, d, h);
-  tile_gemm<L>(acc, a.w0e, ein, lane);
+  AMBER_GEMM(acc, a.w0e, ein, lane);
   tile_act<L>(acc, a.act, stage, lane);
 #pragma unroll 1
   for (int l = 1; l < a.nl; ++l) {
     Tile<L> nxt;
     tile_load_vec<L>(nxt, a.layers[l].b, h);
-    tile_gemm<L>(nxt, a.layers[l].w, acc, lane);
+    AMBER_GEMM(nxt, a.layers[l].w, acc, lane);
     tile_act<L>(nxt, a.act, stage, lane);
     acc = nxt;
   }
@@ -125,9 +140,10 @@ __global__ __launch_bounds__(kBlock) void edge_kernel(const EdgeArgs a, const in
 //            SupervisedMPN.forward (src/algorithm/architecture/supervised_mpn.py:51-54), MLP (mlp.py:60-95)
 // Also used as a generic row-wise dense chain (embedding MLP tail).
 // ---------------------------------------------------------------------------------------------------
-template <int L>
+template <int L, bool B3>
 __global__ __launch_bounds__(kBlock) void node_kernel(const NodeArgs a, const int64_t nblk) {
   __shared__ __attribute__((aligned(16))) float stage_all[kWavesPerBlock * stage_floats<L>()];
+  __shared__ __attribute__((aligned(16))) u32x4 wwin[B3 ? (L / 32) * 3 * 64 : 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 31, h = lane >> 5;
   float* stage = stage_all + wave * stage_floats<L>();
@@ -164,14 +180,14 @@ __global__ __launch_bounds__(kBlock) void node_kernel(const NodeArgs a, const in
     }
     Tile<L> acc;
     tile_load_vec<L>(acc, a.b0, h);
-    tile_gemm<L>(acc, a.w0x, v, lane);
-    tile_gemm<L>(acc, a.w0a, g, lane);
+    AMBER_GEMM(acc, a.w0x, v, lane);
+    AMBER_GEMM(acc, a.w0a, g, lane);
     tile_act<L>(acc, a.act, stage, lane);
 #pragma unroll 1
     for (int l = 1; l < a.nl; ++l) {
       Tile<L> nxt;
       tile_load_vec<L>(nxt, a.layers[l].b, h);
-      tile_gemm<L>(nxt, a.layers[l].w, acc, lane);
+      AMBER_GEMM(nxt, a.layers[l].w, acc, lane);
       tile_act<L>(nxt, a.act, stage, lane);
       acc = nxt;
     }
@@ -191,13 +207,13 @@ __global__ __launch_bounds__(kBlock) void node_kernel(const NodeArgs a, const in
   if (a.do_proj) {
     Tile<L> acc;
     tile_zero<L>(acc);
-    tile_gemm<L>(acc, a.w0s, v, lane);
+    AMBER_GEMM(acc, a.w0s, v, lane);
     __syncthreads();
     tile_stage<L>(stage, acc, c, h);
     __syncthreads();
     stage_store_rows<L>(stage, a.Ps, n0, nvalid, nullptr, lane);
     tile_load_vec<L>(acc, a.b0e, h);
-    tile_gemm<L>(acc, a.w0d, v, lane);
+    AMBER_GEMM(acc, a.w0d, v, lane);
     __syncthreads();
     tile_stage<L>(stage, acc, c, h);
     __syncthreads();
@@ -208,7 +224,7 @@ __global__ __launch_bounds__(kBlock) void node_kernel(const NodeArgs a, const in
     for (int l = 0; l < a.n_dense; ++l) {
       Tile<L> nxt;
       tile_load_vec<L>(nxt, a.dense[l].b, h);
-      tile_gemm<L>(nxt, a.dense[l].w, v, lane);
+      AMBER_GEMM(nxt, a.dense[l].w, v, lane);
       tile_act<L>(nxt, a.dense_act, stage, lane);
       if (a.dense_norm == AMBER_NORM_LAYER)
         tile_layernorm<L>(nxt, a.dense[l].p, a.dense[l].q, 1e-5f, h);
@@ -391,18 +407,18 @@ __global__ void permute_rows_kernel(const float* __restrict__ in, const int32_t*
 // ---------------------------------------------------------------------------------------------------
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
-template <int L>
+template <int L, bool B3 = false>
 static hipError_t launch_edge_t(const EdgeArgs& a, hipStream_t s) {
   const int64_t nblk = cdiv(cdiv(a.E, kTile), kWavesPerBlock);
   if (nblk == 0) return hipSuccess;
-  hipLaunchKernelGGL(edge_kernel<L>, dim3(static_cast<unsigned>(nblk)), dim3(kBlock), 0, s, a, nblk);
+  hipLaunchKernelGGL((edge_kernel<L, B3>), dim3(static_cast<unsigned>(nblk)), dim3(kBlock), 0, s, a, nblk);
   return hipGetLastError();
 }
-template <int L>
+template <int L, bool B3 = false>
 static hipError_t launch_node_t(const NodeArgs& a, hipStream_t s) {
   const int64_t nblk = cdiv(cdiv(a.N, kTile), kWavesPerBlock);
   if (nblk == 0) return hipSuccess;
-  hipLaunchKernelGGL(node_kernel<L>, dim3(static_cast<unsigned>(nblk)), dim3(kBlock), 0, s, a, nblk);
+  hipLaunchKernelGGL((node_kernel<L, B3>), dim3(static_cast<unsigned>(nblk)), dim3(kBlock), 0, s, a, nblk);
   return hipGetLastError();
 }
 template <int L>
@@ -453,7 +469,8 @@ static hipError_t launch_pack_t(const float* W, int ld, int col0, float* out, hi
       return hipErrorInvalidValue;      \
   }
 
-hipError_t launch_edge(int L, const EdgeArgs& a, hipStream_t s) {
+hipError_t launch_edge(int L, int b3, const EdgeArgs& a, hipStream_t s) {
+  if (b3) return fwd_b3_supported(L) ? launch_edge_t<256, true>(a, s) : hipErrorInvalidValue;
   switch (L) {
     case 32: return launch_edge_t<32>(a, s);
     case 64: return launch_edge_t<64>(a, s);
@@ -462,7 +479,8 @@ hipError_t launch_edge(int L, const EdgeArgs& a, hipStream_t s) {
     default: return hipErrorInvalidValue;
   }
 }
-hipError_t launch_node(int L, const NodeArgs& a, hipStream_t s) {
+hipError_t launch_node(int L, int b3, const NodeArgs& a, hipStream_t s) {
+  if (b3) return fwd_b3_supported(L) ? launch_node_t<256, true>(a, s) : hipErrorInvalidValue;
   switch (L) {
     case 32: return launch_node_t<32>(a, s);
     case 64: return launch_node_t<64>(a, s);

@@ -70,8 +70,8 @@ enum {
 /* Static description of the network: the hyper-parameters the reference reads from
  * config/algorithm/architecture/mpn.yaml ("Config / flags"). */
 typedef struct AmberMpnDesc {
-  int32_t latent;             /* latent_dimension: 32, 64, 128, or 256 (256: exact fp32 kernels in every precision mode,
-                                 forward and backward) */
+  int32_t latent;             /* latent_dimension: 32, 64, 128, or 256 (256: row-per-lane kernels - exact fp32 for AMBER_PREC_FP32,
+                                 bf16x3 operands otherwise; backward exact fp32) */
   int32_t num_steps;          /* stack.num_steps: blocks with their own weights */
   int32_t num_step_repeats;   /* stack.num_step_repeats: each block applied this often */
   int32_t mlp_layers;         /* stack.mlp.num_layers, 1..AMBER_MPN_MAX_MLP_LAYERS */
