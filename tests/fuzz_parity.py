@@ -29,7 +29,7 @@ def rel_err(a, b):
 
 
 def random_cfg(rng):
-    latent = int(rng.choice([32, 64, 128], p=[0.25, 0.3, 0.45]))
+    latent = int(rng.choice([32, 64, 128, 256], p=[0.25, 0.3, 0.35, 0.1]))
     act = str(rng.choice(["leakyrelu", "relu", "tanh"], p=[0.5, 0.3, 0.2]))  # LatentMLP's zoo (latent_mlp.py:76-83)
     mode = [None, "inner", "outer"]
     emb = None
