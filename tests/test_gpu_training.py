@@ -475,6 +475,23 @@ def test_decoder_smooth_activations_gradients_match_oracle(gpu_device, dec_act, 
     _check_grads_kink_aware(model, want, flips)  # the stack's leakyrelu has kinks; the decoder's activation has none
 
 
+@pytest.mark.parametrize("n,e", [(5, 0), (1, 0), (33, 0), (40, 3)])
+def test_training_on_edgeless_and_tiny_graphs(gpu_device, n, e):
+    """Graphs without edges (the edge half of every step is skipped, the aggregate is zero), a single node, fewer rows than
+    one 32-row tile: the fused backward kernels' idle waves and empty partials add nothing."""
+    cfg = _cfg(64, 2)
+    g = syn.make_batch([syn.random_graph(n, e, np.random.default_rng(n + e))], [n], 4, 2, seed=3)
+    params = orc.init_params(cfg, seed=13)
+    d = dict(x=g.x, edge_attr=g.edge_attr, edge_index=g.edge_index, batch=g.batch, mask_output=g.mask_output)
+    grad_out = torch.randn(n, 1, generator=torch.Generator().manual_seed(14))
+    model = _model(cfg, params, d, gpu_device).train()
+    out = model(_batch(d, gpu_device))
+    (out * grad_out.to(gpu_device)).sum().backward()
+    want_out, want, flips = _oracle_grads_with_kinks(cfg, params, g.x, g.edge_attr, g.edge_index, g.mask_output, grad_out)
+    assert close(out.detach().cpu(), want_out.float())
+    _check_grads_kink_aware(model, want, flips)
+
+
 def test_latent_256_gradients_match_oracle(gpu_device):
     """The upper end of north_star's width range trains as well (exact fp32 kernels, like its forward): hub rows longer than a
     tile, zero in-degree nodes, a partial mask."""
