@@ -126,8 +126,8 @@ struct NodeArgs {
 };
 
 // b3 = 1: the packed matrices are bf16x3 pieces (AMBER_PACK_B3) and the contractions run on the fp16-rate pipe; built for
-// the latent the split-precision feature-per-lane kernels do not take (256)
-constexpr bool fwd_b3_supported(int L) { return L == 256; }
+// latent 256, which the split-precision feature-per-lane kernels do not take, and for the configurations they do not take at 128
+constexpr bool fwd_b3_supported(int L) { return L == 128 || L == 256; }
 hipError_t launch_edge(int L, int b3, const EdgeArgs& a, hipStream_t s);
 hipError_t launch_node(int L, int b3, const NodeArgs& a, hipStream_t s);
 // out[r] = act(W in[idx(r)] + b): small-K linear (K = F >= 0), idx = perm gather or identity

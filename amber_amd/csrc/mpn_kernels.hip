@@ -470,7 +470,7 @@ static hipError_t launch_pack_t(const float* W, int ld, int col0, float* out, hi
   }
 
 hipError_t launch_edge(int L, int b3, const EdgeArgs& a, hipStream_t s) {
-  if (b3) return fwd_b3_supported(L) ? launch_edge_t<256, true>(a, s) : hipErrorInvalidValue;
+  if (b3) return L == 256 ? launch_edge_t<256, true>(a, s) : (L == 128 ? launch_edge_t<128, true>(a, s) : hipErrorInvalidValue);
   switch (L) {
     case 32: return launch_edge_t<32>(a, s);
     case 64: return launch_edge_t<64>(a, s);
@@ -480,7 +480,7 @@ hipError_t launch_edge(int L, int b3, const EdgeArgs& a, hipStream_t s) {
   }
 }
 hipError_t launch_node(int L, int b3, const NodeArgs& a, hipStream_t s) {
-  if (b3) return fwd_b3_supported(L) ? launch_node_t<256, true>(a, s) : hipErrorInvalidValue;
+  if (b3) return L == 256 ? launch_node_t<256, true>(a, s) : (L == 128 ? launch_node_t<128, true>(a, s) : hipErrorInvalidValue);
   switch (L) {
     case 32: return launch_node_t<32>(a, s);
     case 64: return launch_node_t<64>(a, s);
