@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("AMBER_MPN_LIB") or os.path.join(_HERE, "csrc", "libam
 
 MAX_MLP_LAYERS = 4
 TILE = 32
-NUM_KERNEL_CLASSES = 4
+NUM_KERNEL_CLASSES = 6
 CSR_STATIC_SCRATCH_BYTES = 16 << 20  # AMBER_MPN_CSR_STATIC_SCRATCH_BYTES
 
 ACT = {"relu": 0, "leakyrelu": 1, "tanh": 2, "elu": 3, "swish": 4, "silu": 4, "mish": 5, "gelu": 6}

@@ -160,11 +160,19 @@ def sharded_forward(forward_fn: Callable, batch, rank: int, world_size: int, gat
     buf[: local.shape[0]] = local.to(comm)
     outs = [torch.empty_like(buf) for _ in range(world_size)]
     dist.all_gather(outs, buf, group=group)
+    return reassemble_in_graph_order(batch, [o[:s] for o, s in zip(outs, sizes)], world_size).to(dev)
+
+
+def reassemble_in_graph_order(batch, outs: Sequence[torch.Tensor], world_size: int) -> torch.Tensor:
+    """Per-rank outputs (rank k's rows = the kept nodes of its graphs, ascending graph id) -> rows of the whole batch in
+    graph order.  Rank order equals graph order only when the flattened assignment is already ascending (the contiguous
+    cut); an LPT assignment whose groups happen to be contiguous ranges can still hand a LATER range to an EARLIER rank
+    (weights [5, 17, 20] on 3 ranks -> [[2], [1], [0]]), so everything else goes through the per-graph placement."""
     ptr, eptr, n_g, e_g = graph_sizes(batch)
     groups = assign_graphs(n_g + e_g, world_size)
-    if all(g == list(range(g[0], g[-1] + 1)) for g in groups if g):  # contiguous cuts: rank order is graph order
-        return torch.cat([o[:s] for o, s in zip(outs, sizes)], dim=0).to(dev)
-    # scattered groups: put every graph's rows back at its place (rows a graph contributes = its kept nodes)
+    flat = [g for ids in groups for g in ids]
+    if flat == sorted(flat):
+        return torch.cat(list(outs), dim=0)
     mask = getattr(batch, "mask_output", None)
     kept = np.asarray([int(mask[ptr[g]:ptr[g + 1]].sum()) if mask is not None else int(n_g[g]) for g in range(len(n_g))])
     pieces = [None] * len(n_g)
@@ -173,7 +181,7 @@ def sharded_forward(forward_fn: Callable, batch, rank: int, world_size: int, gat
         for g in g_ids:
             pieces[g] = o[off:off + kept[g]]
             off += kept[g]
-    return torch.cat([p for p in pieces if p is not None], dim=0).to(dev)
+    return torch.cat([p for p in pieces if p is not None], dim=0)
 
 
 def broadcast_buffers(module: torch.nn.Module, src: int = 0, group=None) -> None:

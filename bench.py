@@ -19,23 +19,36 @@ Rank 0 prints one JSON line.
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
-from amber_amd import csr as csr_mod  # noqa: E402
-from amber_amd import _lib, engine, sharding, synthetic as syn  # noqa: E402
-from amber_amd.architecture.supervised_mpn import SupervisedMPN  # noqa: E402
-from amber_amd.config import default_architecture  # noqa: E402
+# torch and the library are imported by _load() AFTER the self-launch decision: the parent of a `--gpus N` run must not
+# touch the GPU (it only starts the ranks, waits for them and passes their exit status on).
+torch = csr_mod = _lib = engine = sharding = syn = SupervisedMPN = default_architecture = None
+
+
+def _load():
+    global torch, csr_mod, _lib, engine, sharding, syn, SupervisedMPN, default_architecture
+    import torch as _torch
+
+    from amber_amd import _lib as lib_, csr as csr_, engine as engine_, sharding as sharding_, synthetic as syn_
+    from amber_amd.architecture.supervised_mpn import SupervisedMPN as model_
+    from amber_amd.config import default_architecture as arch_
+
+    torch, csr_mod, _lib, engine, sharding, syn = _torch, csr_, lib_, engine_, sharding_, syn_
+    SupervisedMPN, default_architecture = model_, arch_
+
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 F16_MFMA_PEAK_TFLOPS = 2500.0  # dense fp16 / bf16 MFMA peak (same guide)
 F32_MFMA_PEAK_TFLOPS = 157.3   # fp32-input MFMA = the fp32 vector rate (same guide)
+RENDEZVOUS_TIMEOUT_S = 120.0   # a rank that cannot join the process group / pass the first barrier in this time exits non-zero
 
 
 def parse():
@@ -74,6 +87,11 @@ def parse():
                     help="initialise the process group (RCCL) even with one rank: exercises on a one-GPU box the RCCL start-up, "
                          "barriers and gathers that the N > 1 runs use (launch under torch.distributed.run --nproc-per-node 1)")
     ap.add_argument("--cpu-graphs", type=int, default=10, help="graphs in the CPU-baseline sample (10 = 1M edges)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="N = 1 headline run: skip the `secondary` object (one-mesh forward, size-capped batch, config-3 training step)")
+    ap.add_argument("--dry-run-rendezvous", action="store_true",
+                    help="test hook for the self-launch path: the ranks only join a gloo group on the CPU, pass a barrier and an "
+                         "all_gather, and rank 0 prints what it saw; no GPU call is made")
     args = ap.parse_args()
     if args.scaling is None:
         args.scaling = "strong" if args.gpus > 1 and args.workload == "config5" and not args.train else "weak"
@@ -86,22 +104,46 @@ def parse():
     return args
 
 
+def host_cores():
+    """(logical CPUs the OS shows, physical cores, CPUs this process may run on)."""
+    logical = os.cpu_count() or 1
+    try:
+        import psutil
+
+        physical = psutil.cpu_count(logical=False) or logical
+    except Exception:  # noqa: BLE001
+        physical = logical
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = logical
+    return logical, physical, usable
+
+
 def cpu_baseline(cfg, state_dict, args):
     """The reference CPU path (oracle = torch-CPU restatement of the reference forward) on the host cores,
-    on a bounded sample of the same workload: `cpu_graphs` of the 120x120 graphs."""
+    on a bounded sample of the same workload: `cpu_graphs` of the 120x120 graphs.  One warm-up forward (thread pool,
+    first-touch allocation), then the median of three."""
     from oracle import mpn_oracle as orc
 
-    threads = min(16, os.cpu_count() or 1)  # the box's CPU share for one GPU is 16
+    logical, physical, usable = host_cores()
+    threads = min(16, usable)  # the box's CPU share for one GPU is 16
     torch.set_num_threads(threads)
     g = syn.grid_batch(num_graphs=args.cpu_graphs, nx=args.nx, ny=args.ny)
     ocfg = dict(cfg, in_node_features=4, in_edge_features=2, embedding=None)
     e = int(g.edge_index.shape[1])
+    times = []
     with torch.no_grad():
-        t0 = time.perf_counter()
-        orc.supervised_mpn_forward(state_dict, ocfg, g.x, g.edge_attr, g.edge_index, g.mask_output)
-        dt = time.perf_counter() - t0
+        for _ in range(4):
+            t0 = time.perf_counter()
+            orc.supervised_mpn_forward(state_dict, ocfg, g.x, g.edge_attr, g.edge_index, g.mask_output)
+            times.append(time.perf_counter() - t0)
+    runs = sorted(times[1:])
+    dt = runs[1]
     return {"value": e / dt, "unit": "edges/s", "cores": threads, "kind": "port",
-            "sample": f"{args.cpu_graphs} of the {args.nx}x{args.ny} graphs (E={e}), one forward, {dt:.1f} s, torch CPU fp32"}
+            "host": {"os_cpu_count": logical, "physical_cores": physical, "usable_cpus": usable},
+            "sample": f"{args.cpu_graphs} of the {args.nx}x{args.ny} graphs (E={e}), median of 3 forwards after 1 warm-up "
+                      f"({', '.join(f'{t:.2f}' for t in times)} s), torch CPU fp32, {threads} threads"}
 
 
 def eager_gpu_baseline(cfg, state_dict, g, dev):
@@ -148,24 +190,119 @@ def measured_traffic(latent: int, edges: int):
     return t.get("edge_kernel_hbm_bytes_per_launch"), t.get("note")
 
 
+def needs_self_launch(args) -> bool:
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (no WORLD_SIZE in the environment)."""
+    return args.gpus > 1 and "WORLD_SIZE" not in os.environ
+
+
+def self_launch(args) -> int:
+    """Start one fresh child process per rank (this same script, same arguments, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set
+    as torch.distributed.run would set them), wait for all of them and return non-zero if any failed.  The parent has made
+    no GPU call and imported neither torch nor the library; the children are ordinary new processes (no re-exec of a process
+    that touched the GPU).  Rank 0's JSON line reaches stdout directly (the children inherit it)."""
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for rank in range(args.gpus):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), AMBER_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC (RCCL needs it)
+        procs.append(subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc, first_failure = 0, None
+    alive = list(range(len(procs)))
+    while alive:
+        time.sleep(0.2)
+        for k in list(alive):
+            r = procs[k].poll()
+            if r is None:
+                continue
+            alive.remove(k)
+            if r != 0 and rc == 0:
+                rc, first_failure = (r if r > 0 else 1), time.monotonic()
+                print(f"bench.py: rank {k} exited with status {r}", file=sys.stderr, flush=True)
+        # a failed rank leaves the others waiting in a collective: give them a moment to notice, then end them (exact PIDs)
+        if first_failure is not None and alive and time.monotonic() - first_failure > 20.0:
+            for k in alive:
+                procs[k].terminate()
+            deadline = time.monotonic() + 10.0
+            for k in alive:
+                try:
+                    procs[k].wait(timeout=max(0.1, deadline - time.monotonic()))
+                except subprocess.TimeoutExpired:
+                    procs[k].kill()
+            alive = []
+    return rc
+
+
+class _Watchdog:
+    """Exit non-zero (with every thread's stack on stderr) instead of hanging when a start-up phase - joining the process
+    group, the first barrier - takes longer than RENDEZVOUS_TIMEOUT_S."""
+
+    def __init__(self, what: str, seconds: float = RENDEZVOUS_TIMEOUT_S):
+        self.what, self.seconds = what, seconds
+
+    def __enter__(self):
+        import faulthandler
+
+        print(f"bench.py[rank {os.environ.get('RANK', 0)}]: {self.what} (watchdog {self.seconds:.0f} s)", file=sys.stderr, flush=True)
+        faulthandler.dump_traceback_later(self.seconds, exit=True)
+        return self
+
+    def __exit__(self, *exc):
+        import faulthandler
+
+        faulthandler.cancel_dump_traceback_later()
+        return False
+
+
 def init_ranks(args):
     """(rank, world, device, dist-or-None): one process per GPU, RCCL (backend "nccl") over xGMI."""
+    import datetime
+
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    if world != args.gpus and world == 1 and args.gpus > 1:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
-    dev = torch.device("cuda", 0 if args.rehearse_on_one_gpu else local_rank)
-    torch.cuda.set_device(dev)
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s)")
+    dev = None
+    if not args.dry_run_rendezvous:
+        if not args.rehearse_on_one_gpu and local_rank >= torch.cuda.device_count():
+            raise SystemExit(f"rank {rank}: no GPU {local_rank} on this node ({torch.cuda.device_count()} visible)")
+        dev = torch.device("cuda", 0 if args.rehearse_on_one_gpu else local_rank)
+        torch.cuda.set_device(dev)
     dist = None
     if world > 1 or args.init_dist:
         import torch.distributed as dist
 
-        if args.rehearse_on_one_gpu:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)
+        limit = datetime.timedelta(seconds=RENDEZVOUS_TIMEOUT_S)
+        with _Watchdog("joining the process group"):
+            if args.rehearse_on_one_gpu or args.dry_run_rendezvous:
+                dist.init_process_group("gloo", timeout=limit)
+            else:
+                dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=600))
+        with _Watchdog("first barrier"):
+            dist.barrier()
+            if dev is not None:
+                torch.cuda.synchronize(dev)
     return rank, world, dev, dist
+
+
+def dry_run_rendezvous(args):
+    """The self-launch path without a GPU: every rank joins, passes a barrier and contributes its rank to an all_gather."""
+    rank, world, _, dist = init_ranks(args)
+    seen = [0]
+    if dist is not None:
+        outs = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(outs, torch.tensor([rank], dtype=torch.int64))
+        seen = [int(o.item()) for o in outs]
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"dry_run_rendezvous": True, "world_size": world, "ranks_seen": seen,
+                          "backend": dist.get_backend() if dist is not None else None,
+                          "self_launched": bool(os.environ.get("AMBER_BENCH_SELF_LAUNCHED"))}), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
 
 
 def gather_floats(vals, dist, dev):
@@ -199,13 +336,13 @@ def timed_steps(step, args, dist, dev):
     return time.perf_counter() - t0, t_local, out
 
 
-def train_bench(args):
-    """Secondary metric (not BASELINE's headline): training-step throughput, edges/s of forward + backward."""
-    rank, world, dev, dist = init_ranks(args)
+def train_steps(dev, dist, rank, *, graphs, nx, ny, latent, mp_steps, steps, warmup):
+    """`steps` timed training steps (forward with tape, backward incl. the gradient all-reduce when there are ranks, Adam)
+    after `warmup` untimed ones.  Returns (seconds, N, E, architecture config)."""
     torch.manual_seed(0)
-    cfg = default_architecture(latent_dimension=args.latent, num_steps=args.mp_steps)
+    cfg = default_architecture(latent_dimension=latent, num_steps=mp_steps)
     model = SupervisedMPN(cfg, syn.GraphBatch(x=torch.zeros(1, 4), edge_attr=torch.zeros(1, 2))).to(dev).train()
-    g = syn.grid_batch(num_graphs=args.graphs, nx=args.nx, ny=args.ny, seed=1234 + rank).to(dev)
+    g = syn.grid_batch(num_graphs=graphs, nx=nx, ny=ny, seed=1234 + rank).to(dev)
     n, e = int(g.x.shape[0]), int(g.edge_index.shape[1])
     g.amber_csr = csr_mod.build_csr(g.edge_index, n)
     target = torch.randn(n, 1, device=dev)
@@ -218,14 +355,14 @@ def train_bench(args):
         opt.step()
         return loss
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     torch.cuda.synchronize(dev)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         loss = step()
     torch.cuda.synchronize(dev)
     if dist is not None:
@@ -233,6 +370,14 @@ def train_bench(args):
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
     assert torch.isfinite(loss)
+    return elapsed, n, e, cfg
+
+
+def train_bench(args):
+    """Secondary metric (not BASELINE's headline): training-step throughput, edges/s of forward + backward."""
+    rank, world, dev, dist = init_ranks(args)
+    elapsed, n, e, cfg = train_steps(dev, dist, rank, graphs=args.graphs, nx=args.nx, ny=args.ny, latent=args.latent,
+                                     mp_steps=args.mp_steps, steps=args.steps, warmup=args.warmup)
     per_rank = gather_floats([float(e) * args.steps, elapsed], dist, dev)
     if rank == 0:
         t = max(r[1] for r in per_rank)
@@ -254,8 +399,61 @@ def train_bench(args):
         dist.destroy_process_group()
 
 
+def small_forward(dev, graphs, calls=50, warmup=10):
+    """The regime AMBER's refinement loop runs in: `graphs` airfoil-sized mesh graphs (144x144 grid each: N = 20,736,
+    E = 144,002) per forward at latent 64 / 20 MP steps (1 = one mesh per _predict, BASELINE configs 2 / 4; 3 = the
+    reference batcher's N + E <= 500k cap, config 3).  Back-to-back calls, CSR cached per mesh."""
+    torch.manual_seed(0)
+    cfg = default_architecture(latent_dimension=64, num_steps=20)
+    model = SupervisedMPN(cfg, syn.GraphBatch(x=torch.zeros(1, 4), edge_attr=torch.zeros(1, 2))).eval().to(dev)
+    g = syn.grid_batch(num_graphs=graphs, nx=144, ny=144).to(dev)
+    n, e = int(g.x.shape[0]), int(g.edge_index.shape[1])
+    g.amber_csr = csr_mod.build_csr(g.edge_index, n)
+    with torch.no_grad():
+        for _ in range(warmup):
+            out = model(g)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(calls):
+            out = model(g)
+        torch.cuda.synchronize(dev)
+        ms = (time.perf_counter() - t0) / calls * 1e3
+        lat = []
+        for _ in range(15):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            model(g)
+            torch.cuda.synchronize(dev)
+            lat.append((time.perf_counter() - t0) * 1e3)
+    assert torch.isfinite(out).all()
+    desc = engine.make_desc(has_head=True, decoder_layers=2, decoder_activation="leakyrelu", decoder_norm=None, **model.mpn.desc_kwargs())
+    pieces, _ = model.decoder_mlp.param_list(single_row=False)
+    flat, packed = engine.PackedParams().get(desc, model.mpn.param_list() + pieces + [model.readout.weight, model.readout.bias])
+    *_, kms, kcnt = engine.forward(desc, flat, packed, g.x, g.edge_attr, g.amber_csr, want_node=False, want_edge=False,
+                                   out_index=None, n_out=n, timed=True)
+    return {"N": n, "E": e, "latent": 64, "mp_steps": 20, "ms_per_forward_pipelined": ms, "edges_per_sec": e / (ms * 1e-3),
+            "ms_per_forward_waited_median": sorted(lat)[len(lat) // 2], "launches_per_forward": int(sum(kcnt[:4])),
+            "calls_timed": calls}
+
+
+def secondary_figures(dev):
+    """What the N = 1 headline run appends AFTER its timed region (a second or so of extra run time): the small-graph
+    forwards and the config-3 training step, so the driver's record carries them too."""
+    steps = 20
+    elapsed, n, e, _ = train_steps(dev, None, 0, graphs=3, nx=144, ny=144, latent=64, mp_steps=20, steps=steps, warmup=5)
+    return {"airfoil1": small_forward(dev, 1), "cap500k": small_forward(dev, 3),
+            "train_config3": {"N": n, "E": e, "latent": 64, "mp_steps": 20, "ms_per_step": elapsed / steps * 1e3,
+                              "edges_per_sec": e * steps / elapsed, "steps_timed": steps,
+                              "what": "forward with tape + backward + Adam, edge_dropout 0.1 with a fresh CSR per step"}}
+
+
 def main():
     args = parse()
+    if needs_self_launch(args):
+        sys.exit(self_launch(args))  # before torch / the library are imported: the parent never touches the GPU
+    _load()
+    if args.dry_run_rendezvous:
+        return dry_run_rendezvous(args)
     if os.environ.get("AMBER_BENCH_WATCHDOG"):  # development: dump every thread's stack and exit if the run takes longer
         import faulthandler
 
@@ -338,7 +536,7 @@ def main():
             gd, n, e, _ = resident(g)
 
     # ---- per-kernel device time, measured live with HIP events on the launch stream (rank 0) ----
-    roofline = roofline_hbm = kernels = cpu = eager = None
+    roofline = roofline_hbm = kernels = cpu = eager = extra = None
     if rank == 0:
         L, S = args.latent, args.mp_steps
         desc = engine.make_desc(has_head=True, decoder_layers=2, decoder_activation="leakyrelu", decoder_norm=None,
@@ -347,8 +545,8 @@ def main():
         flat, packed = engine.PackedParams().get(desc, model.mpn.param_list() + pieces + [model.readout.weight, model.readout.bias])
         ws = engine.workspace(desc, n, e, dev)
         reps = max(1, min(3, args.steps))
-        ms = [0.0] * 4
-        cnt = [0] * 4
+        ms = [0.0] * _lib.NUM_KERNEL_CLASSES
+        cnt = [0] * _lib.NUM_KERNEL_CLASSES
         for _ in range(reps):
             _, _, _, m, c = engine.forward(desc, flat, packed, gd.x, gd.edge_attr, gd.amber_csr, want_node=False, want_edge=False,
                                            out_index=None, n_out=n, ws=ws, timed=True)
@@ -356,9 +554,14 @@ def main():
             cnt = [a + b for a, b in zip(cnt, c)]
         edge_ms = ms[1] / max(cnt[1], 1)   # average duration of one edge-kernel launch
         node_ms = ms[2] / max(cnt[2], 1)
+        # classes 4 / 5 repeat the first edge launch (embedding fused: reads no e) and the last node launch (head fused)
+        steady_edge_ms = (ms[1] - ms[4]) / max(cnt[1] - cnt[4], 1) if cnt[1] > cnt[4] else edge_ms
+        steady_node_ms = (ms[2] - ms[5]) / max(cnt[2] - cnt[5], 1) if cnt[2] > cnt[5] else node_ms
         kernels = {"embed_ms_per_forward": ms[0] / reps, "edge_ms_per_launch": edge_ms, "node_ms_per_launch": node_ms,
+                   "edge_ms_per_launch_steady_state": steady_edge_ms, "edge_ms_first_launch": ms[4] / max(cnt[4], 1),
+                   "node_ms_per_launch_steady_state": steady_node_ms, "node_ms_last_launch": ms[5] / max(cnt[5], 1),
                    "edge_launches_per_forward": cnt[1] // reps, "node_launches_per_forward": cnt[2] // reps,
-                   "device_ms_per_forward": sum(ms) / reps, "csr_build_ms_once_per_mesh": csr_ms}
+                   "device_ms_per_forward": sum(ms[:4]) / reps, "csr_build_ms_once_per_mesh": csr_ms}
         # Dominant kernel = edge_kernel_f2<L> (split-precision fp16x2 MFMA chain, fp32-grade).  Per launch
         # (stated in DESIGN.md):
         #   algorithmic bytes: E * (16 L + 8): read e, gather two node rows, write e', two int32 indices
@@ -366,36 +569,41 @@ def main():
         #   matrix work: E * 4 L^2 useful flops in the weight-split form (direct form E * 8 L^2); every product is
         #   carried out as three fp16 MFMAs, so the matrix pipe executes 3x that
         # With fp16 matrix rates the MFMA floor of a launch (~0.8 ms) lies below its HBM floor (2.5 ms): HBM binds.
+        # `achieved` divides by the STEADY-STATE variant's launch time (the launches that read e, gather two node rows and write
+        # e'): the first launch (no e read) is cheaper and would flatter the figure if averaged in.
         bytes_per_launch = e * (16.0 * L + 8.0)
         flops_useful = e * 4.0 * L * L
-        ach_gbs = bytes_per_launch / (edge_ms * 1e-3) / 1e9
-        ach_tf_exec = 3.0 * flops_useful / (edge_ms * 1e-3) / 1e12
+        ach_gbs = bytes_per_launch / (steady_edge_ms * 1e-3) / 1e9
+        ach_tf_exec = 3.0 * flops_useful / (steady_edge_ms * 1e-3) / 1e12
         traffic, traffic_note = measured_traffic(L, e)
         split = engine.default_precision != "fp32" and L <= 128  # the split-precision kernels ran (else: exact fp32 MFMA)
         if split:
             roofline = {"kernel": f"edge_kernel_f2<{L}>", "bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
-                        "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": edge_ms}
+                        "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": steady_edge_ms,
+                        "avg_launch_ms_all_variants": edge_ms,
+                        "traffic_gbs": (traffic / (steady_edge_ms * 1e-3) / 1e9) if traffic else None,
+                        "traffic_frac_of_peak": (traffic / (steady_edge_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None}
             roofline_hbm = {"kernel": f"edge_kernel_f2<{L}>", "bound": "mfma", "achieved": ach_tf_exec, "peak": F16_MFMA_PEAK_TFLOPS,
                             "unit": "TFLOP/s", "frac": ach_tf_exec / F16_MFMA_PEAK_TFLOPS,
                             "note": "executed fp16 MFMA flops = 3 x useful E*4L^2 (hi*hi, hi*lo, lo*hi); not the binding roof"}
         elif engine.default_precision != "fp32" and L == 256:
             # latent 256 outside the exact mode: the row-per-lane kernels on bf16x3 operands (six bf16 MFMAs a product,
             # matrices streamed once per workgroup through an LDS window); neither roof is close - the larger fraction is named
-            ach_b3 = 6.0 * flops_useful / (edge_ms * 1e-3) / 1e12
+            ach_b3 = 6.0 * flops_useful / (steady_edge_ms * 1e-3) / 1e12
             roofline = {"kernel": f"edge_kernel<{L}, bf16x3>", "bound": "mfma", "achieved": ach_b3, "peak": F16_MFMA_PEAK_TFLOPS,
                         "unit": "TFLOP/s", "frac": ach_b3 / F16_MFMA_PEAK_TFLOPS, "traffic": None,
                         "traffic_note": "executed bf16 MFMA flops = 6 x useful E*4L^2 (three bf16 pieces a float, six piece products)",
-                        "avg_launch_ms": edge_ms}
+                        "avg_launch_ms": steady_edge_ms}
             roofline_hbm = {"kernel": f"edge_kernel<{L}, bf16x3>", "bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": ach_gbs / HBM_PEAK_GBS, "note": "algorithmic bytes E*(16L+8)"}
         else:
             # exact fp32 MFMA (v_mfma_f32_32x32x2_f32 runs at the fp32 vector rate): the matrix pipe binds, not HBM
-            ach_tf = flops_useful / (edge_ms * 1e-3) / 1e12
+            ach_tf = flops_useful / (steady_edge_ms * 1e-3) / 1e12
             roofline = {"kernel": f"edge_kernel<{L}>", "bound": "mfma", "achieved": ach_tf, "peak": F32_MFMA_PEAK_TFLOPS,
                         "unit": "TFLOP/s", "frac": ach_tf / F32_MFMA_PEAK_TFLOPS, "traffic": None,
                         "traffic_note": "exact fp32 path: E*4L^2 fp32 MFMA flops per launch",
-                        "avg_launch_ms": edge_ms}
+                        "avg_launch_ms": steady_edge_ms}
             roofline_hbm = {"kernel": f"edge_kernel<{L}>", "bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": ach_gbs / HBM_PEAK_GBS, "note": "algorithmic bytes E*(16L+8); not the binding roof of the exact path"}
         # host overhead: wall-clock of one model(batch) call that is waited for (what a refinement loop sees per mesh)
@@ -423,11 +631,15 @@ def main():
             fresh.append((time.perf_counter() - t0) * 1e3)
         fresh.sort()
         kernels["wall_ms_per_call_new_mesh_median"] = fresh[len(fresh) // 2]
-        kernels["launches_per_forward"] = sum(cnt) // reps
+        kernels["launches_per_forward"] = sum(cnt[:4]) // reps
         if world == 1 and not args.no_cpu_baseline and args.workload == "config5":
             cpu = cpu_baseline(cfg, state_dict, args)
         if world == 1 and args.eager_baseline:
             eager = eager_gpu_baseline(cfg, state_dict, g, dev)
+        if world == 1 and args.workload == "config5" and args.variant == "grid" and not args.no_secondary:
+            del ws
+            torch.cuda.empty_cache()
+            extra = secondary_figures(dev)
 
     if rank == 0:
         value = total_edges / t
@@ -463,6 +675,8 @@ def main():
                 line[secondary["scaling"] + "_scaling"] = secondary
         if eager is not None:
             line["eager_gpu_baseline"] = eager
+        if extra is not None:
+            line["secondary"] = extra
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -201,8 +201,11 @@ int amber_mpn_forward(const AmberMpnDesc* desc, const float* params, const float
 /* Timing hook for benchmarks: like amber_mpn_forward, and additionally records HIP events around every
  * kernel launch ON `stream` and, after synchronising it, writes per-kernel-class device milliseconds to
  * the HOST array kernel_ms[AMBER_MPN_NUM_KERNEL_CLASSES] (accumulated over the call).  Synchronises. */
-#define AMBER_MPN_NUM_KERNEL_CLASSES 4
-enum { AMBER_KC_EMBED = 0, AMBER_KC_EDGE = 1, AMBER_KC_NODE = 2, AMBER_KC_OTHER = 3 };
+#define AMBER_MPN_NUM_KERNEL_CLASSES 6
+/* EDGE / NODE hold every launch of those kernels; EDGE_FIRST (the first step's launch, which computes the edge embedding
+ * on the fly when it is fused) and NODE_LAST (the last launch, which carries the decoder + readout when the head is fused)
+ * repeat the two launches that differ from the steady-state variant, so a caller can separate them. */
+enum { AMBER_KC_EMBED = 0, AMBER_KC_EDGE = 1, AMBER_KC_NODE = 2, AMBER_KC_OTHER = 3, AMBER_KC_EDGE_FIRST = 4, AMBER_KC_NODE_LAST = 5 };
 int amber_mpn_forward_timed(const AmberMpnDesc* desc, const float* params, const float* packed, int64_t num_nodes,
                             int64_t num_edges, const float* x, const float* edge_attr, const int32_t* rowptr,
                             const int32_t* src_sorted, const int32_t* dst_sorted, const int32_t* perm,

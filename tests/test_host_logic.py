@@ -259,6 +259,58 @@ def test_world_size_2_sharded_forward_equals_unsharded(name):
     assert float((got - want).abs().max() / want.abs().max()) <= 2e-6
 
 
+def _ragged_batch(widths):
+    """One grid graph per entry, node counts ~ widths (N_g + E_g grows with it): sizes chosen so that LPT wins."""
+    rng = np.random.default_rng(11)
+    els, ns = [], []
+    for w in widths:
+        els.append(syn.directed_mesh_edges(syn.grid_triangulation_edges(w, 3), w * 3))
+        ns.append(w * 3)
+    return syn.make_batch(els, ns, 4, 2)
+
+
+@pytest.mark.parametrize("widths, world", [((5, 17, 20), 3), ((20, 18, 25, 4), 4), ((7, 7, 7, 7), 2)])
+def test_reassembly_when_rank_order_is_not_graph_order(widths, world):
+    """LPT groups that are each a contiguous range but handed to the ranks in another order than the
+    graphs' ([5,17,20] on 3 ranks -> [[2],[1],[0]]) must still come back in graph order.  Simulated per-rank outputs: row
+    value = global node id."""
+    g = _ragged_batch(widths)
+    n = g.x.shape[0]
+    ptr, eptr, n_g, e_g = sharding.graph_sizes(g)
+    groups = sharding.assign_graphs(n_g + e_g, world)
+    if widths == (5, 17, 20):
+        assert groups == [[2], [1], [0]]  # the advisor's counter-example really is drawn
+    outs = []
+    for r in range(world):
+        s = sharding.shard_batch(g, r, world)
+        assert s.graph_ids == groups[r]
+        ids = torch.cat([torch.arange(ptr[k], ptr[k + 1]) for k in s.graph_ids]) if s.graph_ids else torch.zeros(0, dtype=torch.int64)
+        assert ids.numel() == s.x.shape[0] and torch.equal(g.x[ids], s.x)
+        outs.append(ids.to(torch.float32).unsqueeze(1))
+    got = sharding.reassemble_in_graph_order(g, outs, world)
+    assert torch.equal(got.flatten(), torch.arange(n, dtype=torch.float32))
+
+
+def _lpt_worker(rank, world, port, ret):
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = _ragged_batch((5, 17, 20))
+    out = sharding.sharded_forward(lambda sub: sub.x[:, :1] * 2.0, g, rank, world)
+    ret[rank] = out.clone()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world_size_3_sharded_forward_with_reversed_lpt_groups():
+    g = _ragged_batch((5, 17, 20))
+    ret = mp.Manager().dict()
+    mp.spawn(_lpt_worker, args=(3, _free_port(), ret), nprocs=3, join=True)
+    for r in range(3):
+        assert torch.equal(ret[r], g.x[:, :1] * 2.0)
+
+
 def _stats_worker(rank, world, port, ret):
     import torch.distributed as dist
 
