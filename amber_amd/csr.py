@@ -32,36 +32,61 @@ class CSR:
         pending = getattr(self, "_pending", None)
         if pending is None:
             return
-        host, event = pending
-        if wait:
-            event.synchronize()
-        elif not event.query():
-            return
+        ring, slot, generation = pending
+        verdict = ring.verdict(slot, generation, wait)
+        if verdict is None:
+            return  # not there yet
         self._pending = None
-        if int(host[0]) != 0:
+        if verdict:
             raise IndexError(f"edge_index contains node ids outside [0, {self.num_nodes})")
 
 
 class _StatusRing:
     """Pinned host words for the deferred status read-backs (allocating pinned memory per mesh would cost more than the
-    synchronisation it avoids).  A slot is handed out again only after its previous owner has been checked."""
+    synchronisation it avoids).  The slot itself holds what the verdict needs - the event behind the copy and the mesh's
+    node count - so it does not depend on the CSR object staying alive: a slot is handed out again only after its previous
+    verdict has been read, and a bad one that nobody has collected is raised there (naming the earlier mesh) rather than
+    dropped."""
 
     def __init__(self, slots: int = 64):
         self.slots = slots
         self.host = None
-        self.owner = [None] * slots
+        self.pending = [None] * slots   # (event, num_nodes) of a verdict nobody has read yet
+        self.generation = [0] * slots
         self.next = 0
 
-    def take(self, csr: "CSR") -> torch.Tensor:
+    def verdict(self, slot: int, generation: int, wait: bool):
+        """True (bad ids) / False (fine) once the word is there, None while it is not.  A slot whose generation has moved
+        on was already read at hand-over (and raised there if it was bad)."""
+        if self.generation[slot] != generation or self.pending[slot] is None:
+            return False
+        event, _ = self.pending[slot]
+        if wait:
+            event.synchronize()
+        elif not event.query():
+            return None
+        self.pending[slot] = None
+        return int(self.host[slot]) != 0
+
+    def take(self):
+        """(slot index, generation, pinned word).  The slot's previous verdict, if still unread, is waited for first."""
         if self.host is None:
             self.host = torch.zeros(self.slots, dtype=torch.int32).pin_memory()
         i = self.next
-        self.next = (i + 1) % self.slots
-        old = self.owner[i]() if self.owner[i] is not None else None
+        old = self.pending[i]
         if old is not None:
-            old.check(wait=True)  # an unchecked build of 64 meshes ago: its verdict must not be lost
-        self.owner[i] = weakref.ref(csr)
-        return self.host[i:i + 1]
+            event, num_nodes = old
+            event.synchronize()
+            self.pending[i] = None  # read now; `next` stays, so the coming build takes this very slot
+            if int(self.host[i]) != 0:
+                raise IndexError(f"an edge_index built {self.slots} meshes ago contained node ids outside [0, {num_nodes}) "
+                                 f"and its CSR was never used again, so this is the first chance to report it")
+        self.next = (i + 1) % self.slots
+        self.generation[i] += 1
+        return i, self.generation[i], self.host[i:i + 1]
+
+    def arm(self, slot: int, event, num_nodes: int) -> None:
+        self.pending[slot] = (event, num_nodes)
 
 
 _status_ring = _StatusRing()
@@ -127,11 +152,12 @@ def build_csr(edge_index: torch.Tensor, num_nodes: int, validate=True) -> CSR:
     _lib.check(rc, "csr_build")
     csr = CSR(N, E, rowptr, src_sorted, dst_sorted, perm)
     if validate == "deferred":
-        host = _status_ring.take(csr)
+        slot, generation, host = _status_ring.take()
         host.copy_(status, non_blocking=True)
         event = torch.cuda.Event()
         event.record(torch.cuda.current_stream(dev))
-        csr._pending = (host, event)
+        _status_ring.arm(slot, event, N)
+        csr._pending = (_status_ring, slot, generation)
     elif validate and int(status.item()) != 0:
         raise IndexError(f"edge_index contains node ids outside [0, {N})")
     return csr

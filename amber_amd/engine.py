@@ -271,6 +271,9 @@ class MpnFunction(torch.autograd.Function):
         lib = _lib.load()
         desc, csr = ctx.desc, ctx.csr
         dev = ctx.x.device
+        # A training step's CSR (that step's kept edges) is built outside any cache and dropped after this call: collect its
+        # deferred index verdict here.  The wait is for the event behind the CSR build, long past by now - not for the forward.
+        csr.check(wait=True)
         n, e = csr.num_nodes, csr.num_edges
         want_node, want_edge, has_sizing = ctx.has
         g_node = _f32c(g_node) if want_node and g_node is not None else None

@@ -404,3 +404,41 @@ def test_deferred_index_validation_surfaces_on_the_model_path(gpu_device):
     ok = csr_mod.build_csr(d["edge_index"].to(gpu_device), int(d["x"].shape[0]), validate="deferred")
     ok.check(wait=True)
     assert getattr(ok, "_pending") is None
+
+
+def test_deferred_verdict_survives_a_dropped_csr_and_the_training_path_collects_it(gpu_device):
+    """(a) a deferred build whose CSR object is dropped unchecked keeps its verdict in the ring slot; the
+    build that takes that slot again reports it, and the slot is then free (the following build succeeds).  (b) the
+    training path builds a CSR per step outside any cache (edge dropout): backward collects its verdict."""
+    cfg, params, d = load_golden("debug_L64_s2")
+    n = int(d["x"].shape[0])
+    bad = d["edge_index"].clone()
+    bad[0, 3] = n + 2
+    good = d["edge_index"].to(gpu_device)
+    ring = csr_mod._status_ring
+    csr = csr_mod.build_csr(bad.to(gpu_device), n, validate="deferred")
+    slot = csr._pending[1]
+    del csr  # nobody ever checks it
+    torch.cuda.synchronize()
+    for _ in range(ring.slots - 1):  # walk the ring round to the same slot
+        csr_mod.build_csr(good, n, validate="deferred").check(wait=True)
+    assert ring.next == slot
+    with pytest.raises(IndexError, match="meshes ago"):
+        csr_mod.build_csr(good, n, validate="deferred")
+    assert ring.next == slot  # not advanced: the next build takes the now-free slot
+    ok = csr_mod.build_csr(good, n, validate="deferred")
+    assert ok._pending[1] == slot
+    ok.check(wait=True)
+
+    # (b) training step with edge dropout on a bad edge list: forward usually raises already, backward certainly does
+    tcfg = dict(cfg, edge_dropout=0.1)
+    model = SupervisedMPN(AttrDict(tcfg), syn.GraphBatch(x=d["x"], edge_attr=d["edge_attr"]))
+    model.load_state_dict(params, strict=True)
+    model = model.to(gpu_device).train()
+    bad2 = d["edge_index"].clone()
+    bad2[1, :] = torch.where(torch.arange(bad2.shape[1]) % 2 == 0, bad2[1, :], torch.full_like(bad2[1, :], n + 5))  # survives dropout
+    g = syn.GraphBatch(x=d["x"].to(gpu_device), edge_attr=d["edge_attr"].to(gpu_device), edge_index=bad2.to(gpu_device),
+                       batch=d["batch"].to(gpu_device), mask_output=d["mask_output"].to(gpu_device))
+    with pytest.raises(IndexError):
+        model(g).sum().backward()
+    torch.cuda.synchronize()

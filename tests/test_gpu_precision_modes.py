@@ -6,7 +6,10 @@
   then the ordinary edge step) to the fp32 bar.
 """
 import os
+import subprocess
+import sys
 
+import numpy as np
 import pytest
 import torch
 
@@ -17,6 +20,7 @@ from test_gpu_parity import _batch, _model_from_golden, _supervised
 
 pytestmark = pytest.mark.gpu
 
+HERE = os.path.dirname(os.path.abspath(__file__))
 F16_TOL = 1e-2
 FP32_TOL = 1e-5
 
@@ -51,25 +55,39 @@ def test_f16_mode_paper_and_synthetic_shapes(gpu_device, f16_mode, latent, steps
     assert err > 1e-7  # the reduced-precision kernels really ran (the exact paths land near 1e-7)
 
 
+def _forward_in_child(tmp_path, tag, fe, **env):
+    """The library reads its environment switches ONCE per process (api.hip: EnvSwitches), so a switch set in this process
+    after the first library call changes nothing: every variant runs in a process of its own."""
+    out = str(tmp_path / f"{tag}.npz")
+    clean = {k: v for k, v in os.environ.items() if k not in ("AMBER_MPN_NO_FUSED_EMBED", "AMBER_MPN_NO_FUSED_HEAD")}
+    r = subprocess.run([sys.executable, os.path.join(HERE, "_fwd_path_worker.py"), out, str(fe)], capture_output=True, text=True,
+                       timeout=240, env=dict(clean, **env))
+    assert r.returncode == 0 and "FWD_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    return torch.from_numpy(np.load(out)["pred"])
+
+
 @pytest.mark.parametrize("fe", [0, 1, 2, 4, 6])
-def test_fused_edge_embedding_matches_separate_embedding(gpu_device, fe):
-    """F_e <= 4 takes the fused first step, F_e = 6 the embedding kernel; with the switch set every width does."""
-    old = engine.default_precision
-    engine.default_precision = "f16x2"
-    try:
-        model, sd, cfg = _supervised(64, 3, 5, fe, gpu_device, seed=11)
-        g = syn.grid_batch(num_graphs=2, nx=23, ny=17, in_node_features=5, in_edge_features=fe)
-        want = orc.supervised_mpn_forward(sd, cfg, g.x, g.edge_attr, g.edge_index, g.mask_output)
-        gd = g.to(gpu_device)
-        with torch.no_grad():
-            fused = model(gd).cpu()
-            os.environ["AMBER_MPN_NO_FUSED_EMBED"] = "1"
-            try:
-                separate = model(gd).cpu()
-            finally:
-                del os.environ["AMBER_MPN_NO_FUSED_EMBED"]
-        assert close(fused, want)
-        assert close(separate, want)
-        assert close(fused, separate)
-    finally:
-        engine.default_precision = old
+def test_fused_edge_embedding_matches_separate_embedding(gpu_device, tmp_path, fe):
+    """F_e <= 4 takes the fused first step (and the node embedding folded into the first projections), F_e = 6 the embedding
+    kernel for the edges; with AMBER_MPN_NO_FUSED_EMBED every width takes the separate kernels.  Both against the oracle,
+    and - the proof that the switch took effect - the two results differ in at least one bit."""
+    _, sd, cfg = _supervised(64, 3, 5, fe, gpu_device, seed=11)
+    g = syn.grid_batch(num_graphs=2, nx=23, ny=17, in_node_features=5, in_edge_features=fe)
+    want = orc.supervised_mpn_forward(sd, cfg, g.x, g.edge_attr, g.edge_index, g.mask_output)
+    fused = _forward_in_child(tmp_path, "fused", fe)
+    separate = _forward_in_child(tmp_path, "separate", fe, AMBER_MPN_NO_FUSED_EMBED="1")
+    assert close(fused, want)
+    assert close(separate, want)
+    assert close(fused, separate)
+    assert not torch.equal(fused, separate)  # other kernels, another summation order: the switch selected them
+
+
+def test_unfused_head_matches_fused_head(gpu_device, tmp_path):
+    """AMBER_MPN_NO_FUSED_HEAD: decoder + readout as a launch of their own instead of riding on the last node launch."""
+    _, sd, cfg = _supervised(64, 3, 5, 2, gpu_device, seed=11)
+    g = syn.grid_batch(num_graphs=2, nx=23, ny=17, in_node_features=5, in_edge_features=2)
+    want = orc.supervised_mpn_forward(sd, cfg, g.x, g.edge_attr, g.edge_index, g.mask_output)
+    fused = _forward_in_child(tmp_path, "head_fused", 2)
+    separate = _forward_in_child(tmp_path, "head_separate", 2, AMBER_MPN_NO_FUSED_HEAD="1")
+    assert close(fused, want) and close(separate, want) and close(fused, separate)
+    assert not torch.equal(fused, separate)
