@@ -11,6 +11,19 @@ from amber_amd.architecture.mlp import MLP
 from amber_amd.mpn.get_message_passing_base import get_mpn_from_graph
 
 
+# Every registration of a Parameter on ANY module (construction, `module.weight = nn.Parameter(...)`) bumps this counter;
+# a cached plan (the module walk's tensor lists) is only valid for the generation it was made in.  One integer compare per
+# forward instead of a walk over ~250 parameters.
+_param_generation = [0]
+
+
+def _note_parameter_registration(module, name, param):
+    _param_generation[0] += 1
+
+
+torch.nn.modules.module.register_module_parameter_registration_hook(_note_parameter_registration)
+
+
 class SupervisedMPN(nn.Module):
     def __init__(self, architecture_config, example_graph):
         """architecture_config: `.latent_dimension`, `.decoder` and `.get(...)` for create_graph_copy,
@@ -43,8 +56,12 @@ class SupervisedMPN(nn.Module):
     def _plan(self, single_row: bool):
         """(desc, flat-buffer pieces, key tensors).  The lists are cached while the decoder's pieces ARE its parameters
         (no BatchNorm folding, no spectral norm: those derive temporaries per call); `_apply`, `train()` and
-        `load_state_dict` drop the cache.  PackedParams still checks every tensor's data pointer and version per call.
-        Not noticed: assigning a NEW Parameter object to a sub-module after the first forward - call `model._plans.clear()`."""
+        `load_state_dict` drop the cache, and so does the registration of a new Parameter object on any module
+        (`model.readout.weight = nn.Parameter(...)`: `_param_generation`).  PackedParams still checks every tensor's data
+        pointer and version per call."""
+        if self._plans.get("generation") != _param_generation[0]:
+            self._plans.clear()
+            self._plans["generation"] = _param_generation[0]
         key = (single_row, engine.default_precision)
         plan = self._plans.get(key)
         if plan is not None:

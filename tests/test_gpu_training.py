@@ -134,9 +134,9 @@ def _oracle_grads_with_kinks(cfg, params, x, edge_attr, edge_index, mask, grad_o
     for (t, o, low, idx), g_out in zip(near, got[len(names):]):
         for i in idx:
             i = tuple(int(v) for v in i)
-            ds = (low - 1.0) if float(t[i]) > 0 else (1.0 - low)  # to the other side's slope
+            ds = (low - 1.0) if float(t.detach()[i]) > 0 else (1.0 - low)  # to the other side's slope
             seed = torch.zeros_like(t)
-            seed[i] = ds * float(g_out[i])
+            seed[i] = ds * float(g_out.detach()[i])
             d = torch.autograd.grad(t, [p[k] for k in names], grad_outputs=seed, retain_graph=True, allow_unused=True)
             flips.append({k: (v if v is not None else torch.zeros_like(p[k])) for k, v in zip(names, d)})
     return out.detach(), grads, flips

@@ -113,8 +113,18 @@ def test_plan_cache_is_dropped_when_parameters_are_recreated():
     cfg["decoder"]["regularization"]["latent_normalization"] = "batch"
     model_bn = SupervisedMPN(cfg, g).eval()
     model_bn._plan(single_row=False)
-    assert model_bn._plans == {}
+    assert [k for k in model_bn._plans if k != "generation"] == []
     assert plan2[0].latent == 32
+    # a caller who REPLACES a Parameter object after the first forward: the plan notices
+    plan3 = model._plan(single_row=False)
+    assert model._plan(single_row=False) is plan3
+    new_w = torch.nn.Parameter(torch.full_like(model.readout.weight, 0.25))
+    model.readout.weight = new_w
+    plan4 = model._plan(single_row=False)
+    assert plan4 is not plan3 and plan4[4][0] is new_w
+    first = model.mpn.message_passing_stack._message_passing_steps[0].edge_module._mlp.mlp_layers[0]
+    first.bias = torch.nn.Parameter(torch.zeros_like(first.bias))
+    assert any(t is first.bias for t in model._plan(single_row=False)[1])
 
 
 def test_factories_and_error_behaviour():
