@@ -511,28 +511,6 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave id as a scalar
   const int n = lane & 31, h = lane >> 5;
 
-  // all layer weights (hi/lo fp16, B-operand order) into LDS, once per workgroup
-  for (int m = EMB ? 1 : 0; m < a.nl; ++m) {
-    const f32x4* src = reinterpret_cast<const f32x4*>(m == 0 ? a.w0e : a.layers[m].w);
-    f32x4* dst = reinterpret_cast<f32x4*>(smem + m * MAT_BYTES);
-    for (int i = tid; i < MAT_BYTES / 16; i += 64 * edge_waves<L>()) dst[i] = src[i];
-  }
-  if constexpr (EMB) {
-    // The fused first step needs no first-layer contraction: e = emb_w attr + emb_b is linear in the raw features, so
-    // W0e e = (W0e emb_w) attr + W0e emb_b.  The folded table [kMaxFusedEmbed + 1][L] (last row: the constant) takes the
-    // place of the first matrix in LDS; every workgroup forms it once (L (F_e + 1) dot products of length L, fp32).
-    float* fold = reinterpret_cast<float*>(smem);
-    for (int o = tid; o < (kMaxFusedEmbed + 1) * L; o += 64 * edge_waves<L>()) {
-      const int k = o / L, j = o - k * L;
-      float sum = 0.f;
-      if (k < a.emb_f || k == kMaxFusedEmbed) {
-        const float* wr = a.emb_w0 + static_cast<int64_t>(j) * (3 * L) + 2 * L;
-        for (int m = 0; m < L; ++m) sum = fmaf(wr[m], k == kMaxFusedEmbed ? a.emb_b[m] : a.emb_w[m * a.emb_f + k], sum);
-      }
-      fold[o] = sum;
-    }
-  }
-  __syncthreads();
   unsigned char* win = smem + a.nl * MAT_BYTES + wave * kWinBytes;
 
   const WinOff wo = make_win_off(lane);
@@ -540,12 +518,27 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
 
   // XCD-aware persistent schedule: blocks b, b+8, ... share an XCD (round-robin dispatch); each XCD walks one
   // contiguous eighth of the tiles with its waves side by side, so gathered P_s rows are shared in that L2.
-  const int64_t xcd = blockIdx.x & 7, local = blockIdx.x >> 3, bpx = gridDim.x >> 3;
-  const int64_t tiles_per_xcd = (ntiles + 7) >> 3;
-  const int64_t t_begin = xcd * tiles_per_xcd;
-  const int64_t t_end = t_begin + tiles_per_xcd < ntiles ? t_begin + tiles_per_xcd : ntiles;
-  const int64_t stride = bpx * edge_waves<L>();
-  int64_t tile = t_begin + local * edge_waves<L>() + wave;
+  // (tile numbers fit 32 bits: E < 2^31; 32-bit scalars keep the loop's bookkeeping out of the spill lanes)
+  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3, bpx = gridDim.x >> 3;
+  const int tiles_per_xcd = static_cast<int>((ntiles + 7) >> 3);
+  const int t_begin = xcd * tiles_per_xcd;
+  const int t_end = t_begin + tiles_per_xcd < static_cast<int>(ntiles) ? t_begin + tiles_per_xcd : static_cast<int>(ntiles);
+  const int stride = bpx * edge_waves<L>();
+  // Round r of this wave.  Full rounds (every wave of the XCD has a tile) keep the contiguous pattern - the waves of a
+  // workgroup side by side.  The LAST, partial round is dealt across the workgroups (tile j of it to workgroup j % bpx,
+  // wave j / bpx) instead of filling the first workgroups' waves: on a one-mesh graph (1.5 tiles a wave) the second
+  // round then loads every CU with half its waves, not half the CUs with all of theirs.
+  const int full_rounds = t_end > t_begin ? (t_end - t_begin) / stride : 0;
+#ifndef AMBER_EDGE_NO_DEAL
+  const int tile_last = t_begin + full_rounds * stride + local + bpx * wave;  // may lie beyond t_end: then the wave has none
+#else
+  const int tile_last = t_begin + full_rounds * stride + local * edge_waves<L>() + wave;
+#endif
+  const int tile_first = t_begin + local * edge_waves<L>() + wave;
+  const int my_tiles = full_rounds + (tile_last < t_end ? 1 : 0);
+  auto tile_of = [&](int r) -> int { return r < full_rounds ? tile_first + r * stride : tile_last; };
+  int rnd = 0;
+  int tile = tile_of(0);
 
   // d: lane c (both halves) holds the destination of tile row c (row boundaries of the per-destination sums); sx / dx:
   // source / destination of row tile_xrow(lane), the form the row broadcasts read (see row_bcast).  The next tile's are
@@ -560,7 +553,7 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
     sx = a.src[px];
     dx = a.dst[px];
   };
-  if (tile < t_end) load_idx(tile, sx0, d0, dx0);
+  if (my_tiles > 0) load_idx(tile, sx0, d0, dx0);
   // Software pipeline over the tiles of a wave (PIPE): the rows of e that open a tile are loaded during the PREVIOUS
   // tile's epilogue (LayerNorm, stores, per-destination sums), when the landing registers of the hidden layer are free,
   // so their latency runs under that work.  Measured at L = 64: -2.4 % per launch (L = 32: +30 %, off).  At L = 128 the 64 loop-carried
@@ -601,19 +594,45 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
     }
   };
   if constexpr (!EMB && AMBER_EDGE_PREFETCH_E != 0) {
-    if (tile < t_end) load_et(tile, 16 * h * L + NFB * n, n);
+    if (my_tiles > 0) load_et(tile, 16 * h * L + NFB * n, n);
   }
+  // (the first tile's indices and rows of e are in flight: the weight prologue below runs under their latency - on a
+  // one-mesh graph a launch is only one or two tiles a wave, so the prologue is a visible share of it)
+  // all layer weights (hi/lo fp16, B-operand order) into LDS, once per workgroup
+  for (int m = EMB ? 1 : 0; m < a.nl; ++m) {
+    const f32x4* src = reinterpret_cast<const f32x4*>(m == 0 ? a.w0e : a.layers[m].w);
+    f32x4* dst = reinterpret_cast<f32x4*>(smem + m * MAT_BYTES);
+    for (int i = tid; i < MAT_BYTES / 16; i += 64 * edge_waves<L>()) dst[i] = src[i];
+  }
+  if constexpr (EMB) {
+    // The fused first step needs no first-layer contraction: e = emb_w attr + emb_b is linear in the raw features, so
+    // W0e e = (W0e emb_w) attr + W0e emb_b.  The folded table [kMaxFusedEmbed + 1][L] (last row: the constant) takes the
+    // place of the first matrix in LDS; every workgroup forms it once (L (F_e + 1) dot products of length L, fp32).
+    float* fold = reinterpret_cast<float*>(smem);
+    for (int o = tid; o < (kMaxFusedEmbed + 1) * L; o += 64 * edge_waves<L>()) {
+      const int k = o / L, j = o - k * L;
+      float sum = 0.f;
+      if (k < a.emb_f || k == kMaxFusedEmbed) {
+        const float* wr = a.emb_w0 + static_cast<int64_t>(j) * (3 * L) + 2 * L;
+        for (int m = 0; m < L; ++m) sum = fmaf(wr[m], k == kMaxFusedEmbed ? a.emb_b[m] : a.emb_w[m * a.emb_f + k], sum);
+      }
+      fold[o] = sum;
+    }
+  }
+  __syncthreads();
 #ifdef AMBER_STAMPS
   unsigned st_acc[kStamps] = {};
   unsigned st_tiles = 0;
   unsigned long long st_prev = __builtin_amdgcn_s_memtime();
 #endif
-  for (; tile < t_end; tile += stride) {
+  for (; rnd < my_tiles; tile = tile_of(++rnd)) {
     STAMP(0);
 #ifdef AMBER_STAMPS
     ++st_tiles;
 #endif
-    const int64_t p0 = tile * kTile;
+    const bool has_next = rnd + 1 < my_tiles;
+    const int tnext = tile_of(rnd + 1);
+    const int64_t p0 = static_cast<int64_t>(tile) * kTile;
     const int nvalid = (a.E - p0) < kTile ? static_cast<int>(a.E - p0) : kTile;  // >= 1: tile < ntiles
     const float* const et_rows = a.e + p0 * L;  // this tile's rows of e (wave-uniform base, 32-bit lane offsets)
     float* const eo = (a.e_out ? a.e_out : a.e) + p0 * L;  // where the updated rows go (training tape: not in place)
@@ -793,7 +812,7 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
     if (a.nl > 1) hidden_layer(a.nl - 1, NoPassHook());
     // the next tile's indices: fetched here, ahead of this tile's stores (a load behind them would wait for them to drain)
     // and after the contractions, whose registers they would otherwise share
-    if (tile + stride < t_end) load_idx(tile + stride, sx1, d1, dx1);
+    if (has_next) load_idx(tnext, sx1, d1, dx1);
     STAMP(6);  // hidden layers
     // ---- residual: the rows of e again (this wave's own loads of a moment ago), now feature per lane ----
     if (EMB && a.residual == AMBER_MODE_INNER) {
@@ -804,7 +823,7 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
       tile_add<L>(acc, et);  // the rows of e, still in their registers
     }
     if constexpr (!EMB && AMBER_EDGE_PREFETCH_E != 0)  // (no branch: the last tile fetches its own rows again, unread)
-      load_et(tile + stride < t_end ? tile + stride : tile, hq, nq);
+      load_et(has_next ? tnext : tile, hq, nq);
     STAMP(7);  // residual
     // ---- LayerNorm over the features of every edge: across the lanes of a half, one register per edge ----
     if (a.layer_norm == AMBER_MODE_INNER && !DBG(64)) tile_layernorm_acc<L>(acc, a.gamma, a.beta, a.eps, nq);
@@ -869,8 +888,8 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
         const bool ends_last = ends_last_i != 0;
         const unsigned mybits = h ? (newseg >> 16) : (newseg & 0xffffu);
         const unsigned anybits = (newseg | (newseg >> 16)) & 0xfffeu;  // wave-uniform: some half ends a row before position i
-        float* const slot_head = a.head + (2 * tile + h) * L + NFB * nq;
-        float* const slot_tail = a.tail + (2 * tile + h) * L + NFB * nq;
+        float* const slot_head = a.head + (2 * static_cast<int64_t>(tile) + h) * L + NFB * nq;
+        float* const slot_tail = a.tail + (2 * static_cast<int64_t>(tile) + h) * L + NFB * nq;
         float* const aggn = a.agg + NFB * nq;
         float sum[NFB];
 #pragma unroll
@@ -971,8 +990,9 @@ __global__ __launch_bounds__(64 * node_waves<L>()) void node_kernel_f2(const Nod
   float marker = 0.f;
   auto marker_load = [&](const float* src) { marker = src[lane]; };
   if (resident) {
+    // all matrices stream in by LDS-DMA; the wait for them sits in the FIRST phase's begin_phase, behind the first tile's
+    // row loads, so that on a one-mesh graph (one or two tiles a wave) the prologue runs under their latency
     for (int k = 0; k < P; ++k) stream_in(mat(k), k);
-    __syncthreads();
   } else {
     stream_in(mat(0), 0);
     marker_load(mat(0));
@@ -983,7 +1003,12 @@ __global__ __launch_bounds__(64 * node_waves<L>()) void node_kernel_f2(const Nod
   // previous phase (whose slot is refilled now) and that every wave's share of this phase's matrix has landed.
   auto begin_phase = [&](int k) -> const unsigned char* {
     int slot = k;
-    if (!resident) {
+    if (resident) {
+      if (gphase == 0) {  // every wave's share of the matrices has landed (vector memory completes in order)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      }
+    } else {
       asm volatile("" ::"v"(marker));  // the compiler waits for the marker load here: this wave's DMA share is in LDS
       if (!DBG(512)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       slot = gphase & 1;
@@ -997,6 +1022,31 @@ __global__ __launch_bounds__(64 * node_waves<L>()) void node_kernel_f2(const Nod
     }
     ++gphase;
     return smem + slot * MAT_BYTES;
+  };
+  // Staggered wave groups (ring mode, AMBER_NODE_STAGGER): the two waves of a SIMD (w and w + waves / 2) pass each phase
+  // barrier at DIFFERENT points of their program - the first group where it always was (after the row work that follows
+  // a contraction, right before the next contraction), the second group right after its contraction, BEFORE that row
+  // work.  Between two barriers the first group then contracts and does row work, the second does (the previous
+  // phase's) row work and contracts: the SIMD's matrix pipe serves one wave at a time and one wave's loads / stores run
+  // under the other's MFMAs, instead of both contracting and then both waiting on memory.  The ring's hand-over rules
+  // are untouched (a wave arrives at barrier k after its contraction k - 1 and after its share of matrix k has landed).
+#ifndef AMBER_NODE_STAGGER
+#define AMBER_NODE_STAGGER 0  // measured in round 3: node launch +1 % (1.251 vs 1.238 ms), see DESIGN.md section 5
+#endif
+  const bool early = AMBER_NODE_STAGGER && !resident && wave >= node_waves<L>() / 2;  // wave-uniform
+  bool pend = false;                  // this wave has already passed the barrier of its next phase
+  const unsigned char* wl_pend = nullptr;
+  auto phase_begin = [&](int kk) -> const unsigned char* {
+    if (!pend) wl_pend = begin_phase(kk);
+    pend = false;
+    return wl_pend;
+  };
+  // after the contraction of a phase; kn = the phase that follows (0 = the next batch's first)
+  auto phase_done = [&](int kn) {
+    if (early && gphase < total_phases) {
+      wl_pend = begin_phase(kn);
+      pend = true;
+    }
   };
 
 #ifdef AMBER_STAMPS
@@ -1061,7 +1111,7 @@ __global__ __launch_bounds__(64 * node_waves<L>()) void node_kernel_f2(const Nod
         pow2_scale(wave_max(landing_absmax<L>(lx)), scale, inv);
         STAMP(1);  // x rows arrived
         tile_zero<L>(acc);  // the first MFMAs take the constant 0 as C; the bias joins the final rescale
-        const unsigned char* wl = begin_phase(k++);
+        const unsigned char* wl = phase_begin(k++);
         STAMP(2);  // barrier
 #ifndef AMBER_NODE_NO_PREFETCH_AGG
         // The rows of sums (agg, or the tail slot when a reduction tile's border cut the row) are fetched under THIS
@@ -1088,6 +1138,7 @@ __global__ __launch_bounds__(64 * node_waves<L>()) void node_kernel_f2(const Nod
             for (int ps = 0; ps < NFB; ++ps) lg.v[ps][it] = pg[ps * 8];
           }
         }
+        phase_done(k < P ? k : 0);
         STAMP(3);  // W0x
       }
       {
@@ -1130,9 +1181,10 @@ __global__ __launch_bounds__(64 * node_waves<L>()) void node_kernel_f2(const Nod
         pow2_scale(wave_max(landing_absmax<L>(lg)), sg, ig);
         tile_scale<L>(acc, sg * inv);
         STAMP(4);  // aggregate rows arrived, mean
-        const unsigned char* wl = begin_phase(k++);
+        const unsigned char* wl = phase_begin(k++);
         STAMP(2);
         if (!DBG(256)) gemm_rows<L, SPLIT, true>(acc, lg, sg, win, wo, wl, lane);
+        phase_done(k < P ? k : 0);
         STAMP(5);  // W0a
         {
           const float post = ig * a.w0x[L * L];
@@ -1149,13 +1201,14 @@ __global__ __launch_bounds__(64 * node_waves<L>()) void node_kernel_f2(const Nod
 #pragma unroll 1
       for (int l = 1; l < a.nl; ++l) {
         STAMP(6);  // bias, activation
-        const unsigned char* wl = begin_phase(k++);
+        const unsigned char* wl = phase_begin(k++);
         STAMP(2);
         const float* wg = a.layers[l].w;
         pow2_scale(wave_max(tile_absmax<L>(acc)), scale, inv);
         Tile<L> nxt;
         tile_zero<L>(nxt);
         if (!DBG(256)) gemm_acc<L, SPLIT, true>(nxt, acc, scale, win, wo, wl, lane);
+        phase_done(k < P ? k : 0);
         STAMP(7);  // hidden layer
         {
           const float post = inv * wg[L * L];
@@ -1245,17 +1298,18 @@ __global__ __launch_bounds__(64 * node_waves<L>()) void node_kernel_f2(const Nod
       pow2_scale(wave_max(tile_absmax<L>(v)), scale, inv);
       {
         STAMP(9);  // store x'
-        const unsigned char* wl = begin_phase(k++);
+        const unsigned char* wl = phase_begin(k++);
         STAMP(2);
         Tile<L> acc;
         tile_zero<L>(acc);
         if (!DBG(256)) gemm_acc<L, SPLIT, true>(acc, v, scale, win, wo, wl, lane);
+        phase_done(k < P ? k : 0);
         tile_scale<L>(acc, inv * a.w0s[L * L]);
         store_tile(a.Ps, acc);
       }
       {
         STAMP(10);  // W0s, store P_s
-        const unsigned char* wl = begin_phase(k++);
+        const unsigned char* wl = phase_begin(k++);
         STAMP(2);
         // x' stays in registers across the first projection.  (Round 1 re-read it here at L = 128, the wave's own stores of
         // a moment ago, for want of registers: with the in-order memory counter that load waited for the stores of x' and
@@ -1286,6 +1340,7 @@ __global__ __launch_bounds__(64 * node_waves<L>()) void node_kernel_f2(const Nod
         Tile<L> acc;
         tile_zero<L>(acc);
         if (!DBG(256)) gemm_acc<L, SPLIT, true>(acc, v, scale, win, wo, wl, lane);
+        phase_done(k < P ? k : 0);
         {
           const float post = inv * a.w0d[L * L];
 #pragma unroll
@@ -1303,13 +1358,14 @@ __global__ __launch_bounds__(64 * node_waves<L>()) void node_kernel_f2(const Nod
     if constexpr (HEAD) {
 #pragma unroll 1
     for (int l = 0; l < a.n_dense; ++l) {
-      const unsigned char* wl = begin_phase(k++);
+      const unsigned char* wl = phase_begin(k++);
       const float* wg = a.dense_f2[l];
       float scale, inv;
       pow2_scale(wave_max(tile_absmax<L>(v)), scale, inv);
       Tile<L> nxt;
       tile_zero<L>(nxt);
       gemm_acc<L, SPLIT, true>(nxt, v, scale, win, wo, wl, lane);
+      phase_done(k < P ? k : 0);
       {
         const float post = inv * wg[L * L];
         float bv[NFB];

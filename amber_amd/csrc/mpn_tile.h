@@ -266,6 +266,15 @@ DEVINL void tile_scale(Tile<L>& t, float factor) {
 template <int L>
 DEVINL void tile_act_fast(Tile<L>& t, int act) {
   const float slope = act == AMBER_ACT_LEAKYRELU ? 0.01f : 0.f;
+#ifdef AMBER_ACT_PK
+  // experiment of round 2 (reverted there: 1e-3 off on 10-20-step networks), kept behind a switch to find the cause
+#pragma unroll
+  for (int fb = 0; fb < L / 32; ++fb) {
+    const f32x16 sv = t.a[fb] * slope;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t.a[fb][i] = fmaxf(t.a[fb][i], sv[i]);
+  }
+#else
 #pragma unroll
   for (int fb = 0; fb < L / 32; ++fb)
 #pragma unroll
@@ -273,6 +282,7 @@ DEVINL void tile_act_fast(Tile<L>& t, int act) {
       const float v = t.a[fb][i];
       t.a[fb][i] = fmaxf(v, slope * v);  // slope in [0, 1): max picks v for v > 0 and slope * v otherwise
     }
+#endif
 }
 
 
