@@ -503,7 +503,12 @@ DEVINL void tile_layernorm_acc(Tile<L>& acc, const float* __restrict__ gamma, co
 __device__ unsigned long long g_stamps[kStamps + 1];
 #endif
 // EMB: first step with the linear edge embedding fused in (e is computed on the fly instead of read)
-template <int L, bool EMB, bool SPLIT>
+// VAR = 0: AMBER's configuration space of the stack (relu / leakyrelu, residual and LayerNorm none or inner) - the kernel of
+// the headline, whose code generation nothing else may disturb.  VAR = 1 (round 3): the general instantiation - tanh as well,
+// and the "outer" residual / LayerNorm (message_passing_block.py:62-74, 127-128), where the per-destination sums are taken
+// from the value BEFORE the outer operations (what the node module aggregates) and the stored e' is the value after them;
+// it reads its rows of e at the tile's top instead of a tile ahead (with an outer residual they are needed to the end).
+template <int L, bool EMB, bool SPLIT, int VAR = 0>
 __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const EdgeArgs a, const int64_t ntiles) {
   constexpr int NFB = L / 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -593,7 +598,8 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
       tile_set_piece<L>(et, i, pc);
     }
   };
-  if constexpr (!EMB && AMBER_EDGE_PREFETCH_E != 0) {
+  constexpr bool PREFETCH_E = !EMB && AMBER_EDGE_PREFETCH_E != 0 && VAR == 0;
+  if constexpr (PREFETCH_E) {
     if (my_tiles > 0) load_et(tile, 16 * h * L + NFB * n, n);
   }
   // (the first tile's indices and rows of e are in flight: the weight prologue below runs under their latency - on a
@@ -708,7 +714,7 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
       if (p > a.E - 1) p = a.E - 1;
       pm = a.perm[p];
     }
-    if constexpr (!EMB && AMBER_EDGE_PREFETCH_E == 0) load_et(tile, hq, nq);
+    if constexpr (!EMB && !PREFETCH_E) load_et(tile, hq, nq);
     gather_ps(sx0, nq);
     Tile<L> acc = pn;
     // The per-destination sums run per HALF over its own sixteen positions (reduction tiles of 16 edges, red_shift 4):
@@ -771,7 +777,7 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
     for (int i = 0; i < 16; ++i)
 #pragma unroll
       for (int fb = 0; fb < NFB; ++fb) acc.a[fb][i] = fmaf(acc.a[fb][i], us, pdp[i][fb]);
-    tile_act_fast<L>(acc, a.act);
+    if constexpr (VAR == 0) tile_act_fast<L>(acc, a.act); else tile_act_var<L>(acc, a.act);
     // Where this half's first row began and its last row ends (rowptr words loaded at the top of the tile).  Taken here,
     // where the in-order memory counter has just been waited down for the P_d rows anyway: read after the stores of e'
     // they would make the wave wait until those stores have drained.
@@ -804,7 +810,7 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
 #pragma unroll
         for (int i = 0; i < 16; ++i) nxt.a[fb][i] = fmaf(nxt.a[fb][i], post, bv[fb]);
       }
-      tile_act_fast<L>(nxt, a.act);
+      if constexpr (VAR == 0) tile_act_fast<L>(nxt, a.act); else tile_act_var<L>(nxt, a.act);
       acc = nxt;
     };
 #pragma unroll 1
@@ -815,23 +821,40 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
     if (has_next) load_idx(tnext, sx1, d1, dx1);
     STAMP(6);  // hidden layers
     // ---- residual: the rows of e again (this wave's own loads of a moment ago), now feature per lane ----
+    auto add_residual = [&]() __attribute__((always_inline)) {
+      if constexpr (EMB) {
+        Tile<L> e0;
+        embed_tile(e0);
+        tile_add<L>(acc, e0);
+      } else {
+        tile_add<L>(acc, et);  // the rows of e, still in their registers
+      }
+    };
     if (EMB && a.residual == AMBER_MODE_INNER) {
-      Tile<L> e0;
-      embed_tile(e0);
-      tile_add<L>(acc, e0);
+      add_residual();
     } else if (res_rows) {
-      tile_add<L>(acc, et);  // the rows of e, still in their registers
+      add_residual();
     }
-    if constexpr (!EMB && AMBER_EDGE_PREFETCH_E != 0)  // (no branch: the last tile fetches its own rows again, unread)
+    if constexpr (PREFETCH_E)  // (no branch: the last tile fetches its own rows again, unread)
       load_et(has_next ? tnext : tile, hq, nq);
     STAMP(7);  // residual
     // ---- LayerNorm over the features of every edge: across the lanes of a half, one register per edge ----
     if (a.layer_norm == AMBER_MODE_INNER && !DBG(64)) tile_layernorm_acc<L>(acc, a.gamma, a.beta, a.eps, nq);
     STAMP(8);  // LayerNorm
+    // "outer" residual / LayerNorm (VAR = 1 only): what the node module aggregates is the value at THIS point
+    // (message_passing_block.py:119-123), so the per-destination sums run first and the outer operations, then the stores
+    // of e', follow them
+    const bool outer_ops = VAR != 0 && (a.residual == AMBER_MODE_OUTER || a.layer_norm == AMBER_MODE_OUTER);
     // (the addresses of the stores and partial sums are formed from here on: derived at the tile's top from the same lane
     // offsets they are live - and spilled - across both contractions)
     asm volatile("" : "+v"(hq), "+v"(nq));
     // ---- stores of e' (two whole 128-byte row pieces per register) ----
+    // (a two-pass loop instead of a lambda for the stores: called through a lambda - even force-inlined - the default
+    // instantiation's tile went through scratch.  VAR = 0: one pass, stores then sums, the straight-line code it always was;
+    // VAR = 1: the sums and the outer operations in pass 0, the stores in pass 0 (no outer operation) or pass 1)
+#pragma unroll
+    for (int pass = 0; pass < (VAR != 0 ? 2 : 1); ++pass) {
+    if (pass == (outer_ops ? 1 : 0)) {
     if (a.write_e || a.out_edge) {
       if (a.write_e && !DBG(16)) {
         if (nvalid == kTile) {
@@ -869,13 +892,17 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
         }
       }
     }
+    }
     STAMP(9);  // stores of e'
+    if (pass == 0) {
     // ---- per-destination sums in CSR order: every lane adds up its own registers (its half's sixteen consecutive
     // edges); a row that ends inside the half goes to agg, rows cut by the half's borders to head / tail of the
     // reduction tile 2 tile + h (see mpn_kernels.hip); the two halves differ only in WHERE their rows end, which the
     // wave handles by predication ----
     {
-      if (nvalid < kTile) {  // positions beyond the end do not count
+      // positions beyond the end do not count: the default instantiation zeroes them in the tile (its rows are stored by
+      // now); the general one, whose tile still goes through the outer operations, skips them in the sums
+      if (VAR == 0 && nvalid < kTile) {
 #pragma unroll
         for (int i = 0; i < 16; ++i)
           if (i + 16 * h >= nvalid) {
@@ -906,7 +933,7 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
             }
           }
 #pragma unroll
-          for (int fb = 0; fb < NFB; ++fb) sum[fb] += acc.a[fb][i];
+          for (int fb = 0; fb < NFB; ++fb) sum[fb] += (VAR == 0 || i + 16 * h < nvalid) ? acc.a[fb][i] : 0.f;
         }
         if (nvh > 0) {
           float* const dstp = (!sb && ends_last) ? aggn + static_cast<size_t>(static_cast<unsigned>(lastd)) * L : (sb ? slot_head : slot_tail);
@@ -914,6 +941,14 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
         }
       }
     }
+    if constexpr (VAR != 0) {
+      if (outer_ops) {
+        if (a.residual == AMBER_MODE_OUTER) add_residual();
+        if (a.layer_norm == AMBER_MODE_OUTER) tile_layernorm_acc<L>(acc, a.gamma, a.beta, a.eps, nq);
+      }
+    }
+    }  // pass == 0
+    }  // passes
     sx0 = sx1;
     d0 = d1;
     dx0 = dx1;
@@ -945,7 +980,9 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
 #ifdef AMBER_STAMPS
 __device__ unsigned long long g_nstamps[kStamps + 1];
 #endif
-template <int L, bool SPLIT, bool HEAD>
+// VAR: as in edge_kernel_f2 (1 = tanh as well, and the residual-outer + LayerNorm-inner order y = LN(m) + x; the other outer
+// combinations are the inner forms for node rows, which have no second consumer)
+template <int L, bool SPLIT, bool HEAD, int VAR = 0>
 __global__ __launch_bounds__(64 * node_waves<L>()) void node_kernel_f2(const NodeArgs a, const int64_t ntiles, const int resident) {
   constexpr int NFB = L / 32;
   constexpr int MAT_BYTES = L * L * 4;
@@ -1196,7 +1233,7 @@ __global__ __launch_bounds__(64 * node_waves<L>()) void node_kernel_f2(const Nod
             for (int i = 0; i < 16; ++i) acc.a[fb][i] = fmaf(acc.a[fb][i], post, bv[fb]);
           }
         }
-        tile_act_fast<L>(acc, a.act);
+        if constexpr (VAR == 0) tile_act_fast<L>(acc, a.act); else tile_act_var<L>(acc, a.act);
       }
 #pragma unroll 1
       for (int l = 1; l < a.nl; ++l) {
@@ -1220,11 +1257,10 @@ __global__ __launch_bounds__(64 * node_waves<L>()) void node_kernel_f2(const Nod
             for (int i = 0; i < 16; ++i) nxt.a[fb][i] = fmaf(nxt.a[fb][i], post, bv[fb]);
           }
         }
-        tile_act_fast<L>(nxt, a.act);
+        if constexpr (VAR == 0) tile_act_fast<L>(nxt, a.act); else tile_act_var<L>(nxt, a.act);
         acc = nxt;
       }
-      // order of message_passing_block.py:124-125: inner residual, inner LayerNorm
-      if (a.residual == AMBER_MODE_INNER) {
+      auto add_x_residual = [&]() __attribute__((always_inline)) {
         AMBER_REPIN_H4;
         if (nvalid == kTile) {
           // one 64-bit address per group of four registers; rows and feature blocks inside it are immediate offsets
@@ -1248,8 +1284,22 @@ __global__ __launch_bounds__(64 * node_waves<L>()) void node_kernel_f2(const Nod
             for (int fb = 0; fb < NFB; ++fb) acc.a[fb][i] += pc[fb];
           }
         }
+      };
+      if constexpr (VAR == 0) {
+        // order of message_passing_block.py:124-125: inner residual, inner LayerNorm
+        if (a.residual == AMBER_MODE_INNER) add_x_residual();
+        if (a.layer_norm == AMBER_MODE_INNER && !DBG(4096)) tile_layernorm_acc<L>(acc, a.gamma, a.beta, a.eps, nq);
+      } else {
+        // message_passing_block.py:124-128: inner residual, inner LayerNorm, outer residual, outer LayerNorm.  Node rows have
+        // no consumer in between, so only residual-outer + LayerNorm-inner differs from "residual, then LayerNorm"
+        if (a.residual == AMBER_MODE_OUTER && a.layer_norm == AMBER_MODE_INNER) {
+          tile_layernorm_acc<L>(acc, a.gamma, a.beta, a.eps, nq);
+          add_x_residual();
+        } else {
+          if (a.residual != AMBER_MODE_NONE) add_x_residual();
+          if (a.layer_norm != AMBER_MODE_NONE) tile_layernorm_acc<L>(acc, a.gamma, a.beta, a.eps, nq);
+        }
       }
-      if (a.layer_norm == AMBER_MODE_INNER && !DBG(4096)) tile_layernorm_acc<L>(acc, a.gamma, a.beta, a.eps, nq);
       v = acc;
     } else {
 #pragma unroll
@@ -1376,7 +1426,7 @@ __global__ __launch_bounds__(64 * node_waves<L>()) void node_kernel_f2(const Nod
           for (int i = 0; i < 16; ++i) nxt.a[fb][i] = fmaf(nxt.a[fb][i], post, bv[fb]);
         }
       }
-      tile_act_fast<L>(nxt, a.dense_act);
+      if constexpr (VAR == 0) tile_act_fast<L>(nxt, a.dense_act); else tile_act_var<L>(nxt, a.dense_act);
       v = nxt;
     }
     if (a.do_readout) {
@@ -1524,23 +1574,28 @@ size_t edge_f2_lds_bytes(int L, int nl) {
 }
 
 bool edge_f2_supported(int L, int nl, int act, int residual, int layer_norm) {
-  return (act == AMBER_ACT_RELU || act == AMBER_ACT_LEAKYRELU) && residual != AMBER_MODE_OUTER &&
-         layer_norm != AMBER_MODE_OUTER && edge_f2_lds_bytes(L, nl) <= 160 * 1024;
+  (void)residual;
+  (void)layer_norm;  // every residual / LayerNorm mode: the outer ones and tanh run on the general instantiation (VAR = 1)
+  return (act == AMBER_ACT_RELU || act == AMBER_ACT_LEAKYRELU || act == AMBER_ACT_TANH) && edge_f2_lds_bytes(L, nl) <= 160 * 1024;
+}
+// the general instantiation is needed for tanh and for an "outer" residual / LayerNorm
+static bool f2_general(int act, int residual, int layer_norm) {
+  return act == AMBER_ACT_TANH || residual == AMBER_MODE_OUTER || layer_norm == AMBER_MODE_OUTER;
 }
 
-template <int L, bool EMB, bool SPLIT>
+template <int L, bool EMB, bool SPLIT, int VAR>
 static hipError_t launch_edge_f2_t(const EdgeArgs& a, int num_cus, hipStream_t s) {
   const int64_t ntiles = (a.E + kTile - 1) / kTile;
   if (ntiles == 0) return hipSuccess;
   const size_t lds = edge_f2_lds_bytes(L, a.nl);
-  hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(edge_kernel_f2<L, EMB, SPLIT>), lds);
+  hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(edge_kernel_f2<L, EMB, SPLIT, VAR>), lds);
   if (e != hipSuccess) return e;
   const int64_t grid = persistent_grid(num_cus, ntiles, edge_waves<L>());
 #ifdef AMBER_STAMPS
   unsigned long long zero[kStamps + 1] = {};
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), zero, sizeof(zero));
 #endif
-  hipLaunchKernelGGL((edge_kernel_f2<L, EMB, SPLIT>), dim3(static_cast<unsigned>(grid)), dim3(64 * edge_waves<L>()), lds, s, a, ntiles);
+  hipLaunchKernelGGL((edge_kernel_f2<L, EMB, SPLIT, VAR>), dim3(static_cast<unsigned>(grid)), dim3(64 * edge_waves<L>()), lds, s, a, ntiles);
 #ifdef AMBER_STAMPS
   {
     (void)hipStreamSynchronize(s);
@@ -1556,10 +1611,14 @@ static hipError_t launch_edge_f2_t(const EdgeArgs& a, int num_cus, hipStream_t s
 #endif
   return hipGetLastError();
 }
+template <int L, int VAR>
+static hipError_t launch_edge_f2_v(const EdgeArgs& a, int num_cus, hipStream_t s) {
+  if (a.single) return a.emb_on ? launch_edge_f2_t<L, true, false, VAR>(a, num_cus, s) : launch_edge_f2_t<L, false, false, VAR>(a, num_cus, s);
+  return a.emb_on ? launch_edge_f2_t<L, true, true, VAR>(a, num_cus, s) : launch_edge_f2_t<L, false, true, VAR>(a, num_cus, s);
+}
 template <int L>
 static hipError_t launch_edge_f2_l(const EdgeArgs& a, int num_cus, hipStream_t s) {
-  if (a.single) return a.emb_on ? launch_edge_f2_t<L, true, false>(a, num_cus, s) : launch_edge_f2_t<L, false, false>(a, num_cus, s);
-  return a.emb_on ? launch_edge_f2_t<L, true, true>(a, num_cus, s) : launch_edge_f2_t<L, false, true>(a, num_cus, s);
+  return f2_general(a.act, a.residual, a.layer_norm) ? launch_edge_f2_v<L, 1>(a, num_cus, s) : launch_edge_f2_v<L, 0>(a, num_cus, s);
 }
 
 hipError_t launch_edge_f2(int L, const EdgeArgs& a, int num_cus, hipStream_t s) {
@@ -1574,14 +1633,17 @@ hipError_t launch_edge_f2(int L, const EdgeArgs& a, int num_cus, hipStream_t s) 
 }
 
 bool node_f2_supported(int L, int act, int residual, int layer_norm) {
-  return L <= 128 && (act == AMBER_ACT_RELU || act == AMBER_ACT_LEAKYRELU) && residual != AMBER_MODE_OUTER && layer_norm != AMBER_MODE_OUTER;
+  (void)residual;
+  (void)layer_norm;  // every mode: see f2_general
+  return L <= 128 && (act == AMBER_ACT_RELU || act == AMBER_ACT_LEAKYRELU || act == AMBER_ACT_TANH);
 }
 
 bool head_f2_supported(int n_dense, int dense_act, int dense_norm) {
-  return n_dense >= 1 && (dense_act == AMBER_ACT_RELU || dense_act == AMBER_ACT_LEAKYRELU) && dense_norm == AMBER_NORM_NONE;
+  return n_dense >= 1 && (dense_act == AMBER_ACT_RELU || dense_act == AMBER_ACT_LEAKYRELU || dense_act == AMBER_ACT_TANH) &&
+         dense_norm == AMBER_NORM_NONE;
 }
 
-template <int L, bool SPLIT, bool HEAD>
+template <int L, bool SPLIT, bool HEAD, int VAR>
 static hipError_t launch_node_f2_t(const NodeArgs& a, int num_cus, hipStream_t s) {
   const int64_t ntiles = (a.N + kTile - 1) / kTile;
   if (ntiles == 0 || (!a.do_update && !a.do_proj && !HEAD)) return hipSuccess;
@@ -1590,14 +1652,14 @@ static hipError_t launch_node_f2_t(const NodeArgs& a, int num_cus, hipStream_t s
   const size_t mat = static_cast<size_t>(L) * L * 4, wins = static_cast<size_t>(node_waves<L>()) * kWinBytes;
   const int resident = P * mat + wins <= 160 * 1024 ? 1 : 0;
   const size_t lds = (resident ? P : 2) * mat + wins;
-  hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(node_kernel_f2<L, SPLIT, HEAD>), lds);
+  hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(node_kernel_f2<L, SPLIT, HEAD, VAR>), lds);
   if (e != hipSuccess) return e;
   const int64_t grid = persistent_grid(num_cus, ntiles, node_waves<L>());
 #ifdef AMBER_STAMPS
   unsigned long long zero[kStamps + 1] = {};
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_nstamps), zero, sizeof(zero));
 #endif
-  hipLaunchKernelGGL((node_kernel_f2<L, SPLIT, HEAD>), dim3(static_cast<unsigned>(grid)), dim3(64 * node_waves<L>()), lds, s, a, ntiles, resident);
+  hipLaunchKernelGGL((node_kernel_f2<L, SPLIT, HEAD, VAR>), dim3(static_cast<unsigned>(grid)), dim3(64 * node_waves<L>()), lds, s, a, ntiles, resident);
 #ifdef AMBER_STAMPS
   {
     (void)hipStreamSynchronize(s);
@@ -1615,11 +1677,16 @@ static hipError_t launch_node_f2_t(const NodeArgs& a, int num_cus, hipStream_t s
   return hipGetLastError();
 }
 
+template <int L, int VAR>
+static hipError_t launch_node_f2_v(const NodeArgs& a, int num_cus, hipStream_t s) {
+  const bool head = a.do_readout != 0;  // the caller (run_node) clears the head fields unless it rides on this launch
+  if (a.single) return head ? launch_node_f2_t<L, false, true, VAR>(a, num_cus, s) : launch_node_f2_t<L, false, false, VAR>(a, num_cus, s);
+  return head ? launch_node_f2_t<L, true, true, VAR>(a, num_cus, s) : launch_node_f2_t<L, true, false, VAR>(a, num_cus, s);
+}
 template <int L>
 static hipError_t launch_node_f2_l(const NodeArgs& a, int num_cus, hipStream_t s) {
-  const bool head = a.do_readout != 0;  // the caller (run_node) clears the head fields unless it rides on this launch
-  if (a.single) return head ? launch_node_f2_t<L, false, true>(a, num_cus, s) : launch_node_f2_t<L, false, false>(a, num_cus, s);
-  return head ? launch_node_f2_t<L, true, true>(a, num_cus, s) : launch_node_f2_t<L, true, false>(a, num_cus, s);
+  const bool general = (a.do_update && f2_general(a.act, a.residual, a.layer_norm)) || (a.do_readout && a.dense_act == AMBER_ACT_TANH);
+  return general ? launch_node_f2_v<L, 1>(a, num_cus, s) : launch_node_f2_v<L, 0>(a, num_cus, s);
 }
 hipError_t launch_node_f2(int L, const NodeArgs& a, int num_cus, hipStream_t s) {
   switch (L) {

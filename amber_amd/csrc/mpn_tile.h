@@ -285,5 +285,34 @@ DEVINL void tile_act_fast(Tile<L>& t, int act) {
 #endif
 }
 
+// tanh on accumulator registers for the feature-per-lane kernels (no LDS trip, no library call), two ranges that share one
+// v_rcp_f32:  |x| < 0.8: the Pade [5/4] form as a CORRECTION to x,  tanh x = x - x x^2 (315 + 14 x^2) / (945 + 420 x^2 + 15 x^4)
+// (truncation < 5e-9 there; the roundings only touch the correction, so tiny arguments keep their relative accuracy);
+// otherwise sign(x) (1 - 2 / (exp(2 |x|) + 1)) with v_exp_f32 - exp overflows to +inf for |x| > 44, the quotient becomes 0 and
+// the result saturates at 1.  Relative error <= ~2e-7 everywhere (checked against float64 over [-6, 6] in steps of 6e-6 and
+// around 0).  reference: torch.nn.Tanh in LatentMLP (src/mpn/common/latent_mlp.py:76-83)
+DEVINL float tanh_fast(float x) {
+  const float ax = fabsf(x), x2 = x * x;
+  const float n = fmaf(14.0f, x2, 315.0f);
+  const float d = fmaf(fmaf(15.0f, x2, 420.0f), x2, 945.0f);
+  const float t = __builtin_amdgcn_exp2f(2.885390081777927f * ax);  // exp(2 |x|)
+  const bool small = ax < 0.8f;
+  const float r = __builtin_amdgcn_rcpf(small ? d : t + 1.0f);
+  const float ra = fmaf(-x, x2 * (n * r), x);
+  const float rb = copysignf(fmaf(-2.0f, r, 1.0f), x);
+  return small ? ra : rb;
+}
+// relu / leakyrelu / tanh (the "general" instantiations of the feature-per-lane kernels)
+template <int L>
+DEVINL void tile_act_var(Tile<L>& t, int act) {
+  if (act == AMBER_ACT_TANH) {
+#pragma unroll
+    for (int fb = 0; fb < L / 32; ++fb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) t.a[fb][i] = tanh_fast(t.a[fb][i]);
+  } else {
+    tile_act_fast<L>(t, act);
+  }
+}
 
 }  // namespace amber

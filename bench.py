@@ -76,6 +76,10 @@ def parse():
                     help="secondary benchmark: one training step (forward with tape + backward + gradient all-reduce) on a "
                          "BASELINE config 3 shaped batch (airfoil: 3 graphs of ~20.7k nodes / 144k edges, latent 64, 20 MP steps) "
                          "unless --graphs/--nx/--ny/--latent/--mp-steps are given")
+    ap.add_argument("--activation", choices=["leakyrelu", "relu", "tanh"], default="leakyrelu",
+                    help="stack.mlp.activation_function (secondary lines: the headline is leakyrelu, the reference's default)")
+    ap.add_argument("--residual", choices=["inner", "outer", "none"], default="inner", help="stack.residual_connections")
+    ap.add_argument("--layer-norm", choices=["inner", "outer", "none"], default="inner", help="stack.layer_norm")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager-baseline", action="store_true",
                     help="also time the reference's formulation as PyTorch-ROCm eager ops on this GPU (the oracle's op sequence "
@@ -467,6 +471,11 @@ def main():
     # ---- network: BASELINE config 5 (latent 128, 10 MP steps, inner residual + inner LN, leakyrelu) ----
     torch.manual_seed(0)
     cfg = default_architecture(latent_dimension=args.latent, num_steps=args.mp_steps)
+    default_modes = (args.activation, args.residual, args.layer_norm) == ("leakyrelu", "inner", "inner")
+    if not default_modes:  # secondary lines: the other modes mpn.yaml can express
+        cfg["stack"]["mlp"]["activation_function"] = args.activation
+        cfg["stack"]["residual_connections"] = None if args.residual == "none" else args.residual
+        cfg["stack"]["layer_norm"] = None if args.layer_norm == "none" else args.layer_norm
     example = syn.GraphBatch(x=torch.zeros(1, 4), edge_attr=torch.zeros(1, 2))
     model = SupervisedMPN(cfg, example).eval()
     state_dict = {k: v.clone() for k, v in model.state_dict().items()}
@@ -632,11 +641,11 @@ def main():
         fresh.sort()
         kernels["wall_ms_per_call_new_mesh_median"] = fresh[len(fresh) // 2]
         kernels["launches_per_forward"] = sum(cnt[:4]) // reps
-        if world == 1 and not args.no_cpu_baseline and args.workload == "config5":
+        if world == 1 and not args.no_cpu_baseline and args.workload == "config5" and default_modes:
             cpu = cpu_baseline(cfg, state_dict, args)
         if world == 1 and args.eager_baseline:
             eager = eager_gpu_baseline(cfg, state_dict, g, dev)
-        if world == 1 and args.workload == "config5" and args.variant == "grid" and not args.no_secondary:
+        if world == 1 and args.workload == "config5" and args.variant == "grid" and default_modes and not args.no_secondary:
             del ws
             torch.cuda.empty_cache()
             extra = secondary_figures(dev)
@@ -657,7 +666,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "precision": engine.default_precision, "data": "synthetic",
             "config": {"workload": f"{what} per "
                                    f"{'GPU' if args.scaling == 'weak' else 'job'}, N={n} E={e} on rank 0, F_n=4 F_e=2, latent {args.latent}, "
-                                   f"{args.mp_steps} MP steps, inner residual + inner LayerNorm, leakyrelu, decoder + readout",
+                                   f"{args.mp_steps} MP steps, {args.residual} residual + {args.layer_norm} LayerNorm, {args.activation}, decoder + readout",
                        "global_edges_per_step": total_edges / args.steps, "parallelism": f"graph-wise dp{world}, no collective",
                        "backend": dist.get_backend() if dist is not None else None,
                        "world_size": dist.get_world_size() if dist is not None else 1},
