@@ -508,9 +508,11 @@ __device__ unsigned long long g_stamps[kStamps + 1];
 // and the "outer" residual / LayerNorm (message_passing_block.py:62-74, 127-128), where the per-destination sums are taken
 // from the value BEFORE the outer operations (what the node module aggregates) and the stored e' is the value after them;
 // it reads its rows of e at the tile's top instead of a tile ahead (with an outer residual they are needed to the end).
+// VAR = 2: the default structure with tanh as the activation (no outer mode).
 template <int L, bool EMB, bool SPLIT, int VAR = 0>
 __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const EdgeArgs a, const int64_t ntiles) {
   constexpr int NFB = L / 32;
+  constexpr bool GEN = (VAR & 1) != 0;  // general epilogue (outer modes); VAR = 2: the default structure with tanh
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int MAT_BYTES = L * L * 4;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave id as a scalar
@@ -598,7 +600,7 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
       tile_set_piece<L>(et, i, pc);
     }
   };
-  constexpr bool PREFETCH_E = !EMB && AMBER_EDGE_PREFETCH_E != 0 && VAR == 0;
+  constexpr bool PREFETCH_E = !EMB && AMBER_EDGE_PREFETCH_E != 0 && !GEN;
   if constexpr (PREFETCH_E) {
     if (my_tiles > 0) load_et(tile, 16 * h * L + NFB * n, n);
   }
@@ -777,7 +779,7 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
     for (int i = 0; i < 16; ++i)
 #pragma unroll
       for (int fb = 0; fb < NFB; ++fb) acc.a[fb][i] = fmaf(acc.a[fb][i], us, pdp[i][fb]);
-    if constexpr (VAR == 0) tile_act_fast<L>(acc, a.act); else tile_act_var<L>(acc, a.act);
+    if constexpr (VAR == 0) tile_act_fast<L>(acc, a.act); else if constexpr (VAR == 2) tile_tanh<L>(acc); else tile_act_var<L>(acc, a.act);
     // Where this half's first row began and its last row ends (rowptr words loaded at the top of the tile).  Taken here,
     // where the in-order memory counter has just been waited down for the P_d rows anyway: read after the stores of e'
     // they would make the wave wait until those stores have drained.
@@ -810,7 +812,7 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
 #pragma unroll
         for (int i = 0; i < 16; ++i) nxt.a[fb][i] = fmaf(nxt.a[fb][i], post, bv[fb]);
       }
-      if constexpr (VAR == 0) tile_act_fast<L>(nxt, a.act); else tile_act_var<L>(nxt, a.act);
+      if constexpr (VAR == 0) tile_act_fast<L>(nxt, a.act); else if constexpr (VAR == 2) tile_tanh<L>(nxt); else tile_act_var<L>(nxt, a.act);
       acc = nxt;
     };
 #pragma unroll 1
@@ -844,7 +846,7 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
     // "outer" residual / LayerNorm (VAR = 1 only): what the node module aggregates is the value at THIS point
     // (message_passing_block.py:119-123), so the per-destination sums run first and the outer operations, then the stores
     // of e', follow them
-    const bool outer_ops = VAR != 0 && (a.residual == AMBER_MODE_OUTER || a.layer_norm == AMBER_MODE_OUTER);
+    const bool outer_ops = GEN && (a.residual == AMBER_MODE_OUTER || a.layer_norm == AMBER_MODE_OUTER);
     // (the addresses of the stores and partial sums are formed from here on: derived at the tile's top from the same lane
     // offsets they are live - and spilled - across both contractions)
     asm volatile("" : "+v"(hq), "+v"(nq));
@@ -853,7 +855,7 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
     // instantiation's tile went through scratch.  VAR = 0: one pass, stores then sums, the straight-line code it always was;
     // VAR = 1: the sums and the outer operations in pass 0, the stores in pass 0 (no outer operation) or pass 1)
 #pragma unroll
-    for (int pass = 0; pass < (VAR != 0 ? 2 : 1); ++pass) {
+    for (int pass = 0; pass < (GEN ? 2 : 1); ++pass) {
     if (pass == (outer_ops ? 1 : 0)) {
     if (a.write_e || a.out_edge) {
       if (a.write_e && !DBG(16)) {
@@ -902,7 +904,7 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
     {
       // positions beyond the end do not count: the default instantiation zeroes them in the tile (its rows are stored by
       // now); the general one, whose tile still goes through the outer operations, skips them in the sums
-      if (VAR == 0 && nvalid < kTile) {
+      if (!GEN && nvalid < kTile) {
 #pragma unroll
         for (int i = 0; i < 16; ++i)
           if (i + 16 * h >= nvalid) {
@@ -933,7 +935,7 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
             }
           }
 #pragma unroll
-          for (int fb = 0; fb < NFB; ++fb) sum[fb] += (VAR == 0 || i + 16 * h < nvalid) ? acc.a[fb][i] : 0.f;
+          for (int fb = 0; fb < NFB; ++fb) sum[fb] += (!GEN || i + 16 * h < nvalid) ? acc.a[fb][i] : 0.f;
         }
         if (nvh > 0) {
           float* const dstp = (!sb && ends_last) ? aggn + static_cast<size_t>(static_cast<unsigned>(lastd)) * L : (sb ? slot_head : slot_tail);
@@ -941,7 +943,7 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
         }
       }
     }
-    if constexpr (VAR != 0) {
+    if constexpr (GEN) {
       if (outer_ops) {
         if (a.residual == AMBER_MODE_OUTER) add_residual();
         if (a.layer_norm == AMBER_MODE_OUTER) tile_layernorm_acc<L>(acc, a.gamma, a.beta, a.eps, nq);
@@ -1233,7 +1235,7 @@ __global__ __launch_bounds__(64 * node_waves<L>()) void node_kernel_f2(const Nod
             for (int i = 0; i < 16; ++i) acc.a[fb][i] = fmaf(acc.a[fb][i], post, bv[fb]);
           }
         }
-        if constexpr (VAR == 0) tile_act_fast<L>(acc, a.act); else tile_act_var<L>(acc, a.act);
+        if constexpr (VAR == 0) tile_act_fast<L>(acc, a.act); else if constexpr (VAR == 2) tile_tanh<L>(acc); else tile_act_var<L>(acc, a.act);
       }
 #pragma unroll 1
       for (int l = 1; l < a.nl; ++l) {
@@ -1257,7 +1259,7 @@ __global__ __launch_bounds__(64 * node_waves<L>()) void node_kernel_f2(const Nod
             for (int i = 0; i < 16; ++i) nxt.a[fb][i] = fmaf(nxt.a[fb][i], post, bv[fb]);
           }
         }
-        if constexpr (VAR == 0) tile_act_fast<L>(nxt, a.act); else tile_act_var<L>(nxt, a.act);
+        if constexpr (VAR == 0) tile_act_fast<L>(nxt, a.act); else if constexpr (VAR == 2) tile_tanh<L>(nxt); else tile_act_var<L>(nxt, a.act);
         acc = nxt;
       }
       auto add_x_residual = [&]() __attribute__((always_inline)) {
@@ -1285,7 +1287,7 @@ __global__ __launch_bounds__(64 * node_waves<L>()) void node_kernel_f2(const Nod
           }
         }
       };
-      if constexpr (VAR == 0) {
+      if constexpr ((VAR & 1) == 0) {
         // order of message_passing_block.py:124-125: inner residual, inner LayerNorm
         if (a.residual == AMBER_MODE_INNER) add_x_residual();
         if (a.layer_norm == AMBER_MODE_INNER && !DBG(4096)) tile_layernorm_acc<L>(acc, a.gamma, a.beta, a.eps, nq);
@@ -1578,9 +1580,10 @@ bool edge_f2_supported(int L, int nl, int act, int residual, int layer_norm) {
   (void)layer_norm;  // every residual / LayerNorm mode: the outer ones and tanh run on the general instantiation (VAR = 1)
   return (act == AMBER_ACT_RELU || act == AMBER_ACT_LEAKYRELU || act == AMBER_ACT_TANH) && edge_f2_lds_bytes(L, nl) <= 160 * 1024;
 }
-// the general instantiation is needed for tanh and for an "outer" residual / LayerNorm
-static bool f2_general(int act, int residual, int layer_norm) {
-  return act == AMBER_ACT_TANH || residual == AMBER_MODE_OUTER || layer_norm == AMBER_MODE_OUTER;
+// which instantiation: 1 = general (an "outer" residual / LayerNorm; takes tanh too), 2 = the default structure with tanh
+static int f2_variant(int act, int residual, int layer_norm) {
+  if (residual == AMBER_MODE_OUTER || layer_norm == AMBER_MODE_OUTER) return 1;
+  return act == AMBER_ACT_TANH ? 2 : 0;
 }
 
 template <int L, bool EMB, bool SPLIT, int VAR>
@@ -1618,7 +1621,11 @@ static hipError_t launch_edge_f2_v(const EdgeArgs& a, int num_cus, hipStream_t s
 }
 template <int L>
 static hipError_t launch_edge_f2_l(const EdgeArgs& a, int num_cus, hipStream_t s) {
-  return f2_general(a.act, a.residual, a.layer_norm) ? launch_edge_f2_v<L, 1>(a, num_cus, s) : launch_edge_f2_v<L, 0>(a, num_cus, s);
+  switch (f2_variant(a.act, a.residual, a.layer_norm)) {
+    case 1: return launch_edge_f2_v<L, 1>(a, num_cus, s);
+    case 2: return launch_edge_f2_v<L, 2>(a, num_cus, s);
+    default: return launch_edge_f2_v<L, 0>(a, num_cus, s);
+  }
 }
 
 hipError_t launch_edge_f2(int L, const EdgeArgs& a, int num_cus, hipStream_t s) {
@@ -1685,7 +1692,8 @@ static hipError_t launch_node_f2_v(const NodeArgs& a, int num_cus, hipStream_t s
 }
 template <int L>
 static hipError_t launch_node_f2_l(const NodeArgs& a, int num_cus, hipStream_t s) {
-  const bool general = (a.do_update && f2_general(a.act, a.residual, a.layer_norm)) || (a.do_readout && a.dense_act == AMBER_ACT_TANH);
+  // (the node kernel's general instantiation costs nothing measurable: one variant serves tanh and the outer order)
+  const bool general = (a.do_update && f2_variant(a.act, a.residual, a.layer_norm) != 0) || (a.do_readout && a.dense_act == AMBER_ACT_TANH);
   return general ? launch_node_f2_v<L, 1>(a, num_cus, s) : launch_node_f2_v<L, 0>(a, num_cus, s);
 }
 hipError_t launch_node_f2(int L, const NodeArgs& a, int num_cus, hipStream_t s) {

@@ -302,14 +302,18 @@ DEVINL float tanh_fast(float x) {
   const float rb = copysignf(fmaf(-2.0f, r, 1.0f), x);
   return small ? ra : rb;
 }
+template <int L>
+DEVINL void tile_tanh(Tile<L>& t) {
+#pragma unroll
+  for (int fb = 0; fb < L / 32; ++fb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t.a[fb][i] = tanh_fast(t.a[fb][i]);
+}
 // relu / leakyrelu / tanh (the "general" instantiations of the feature-per-lane kernels)
 template <int L>
 DEVINL void tile_act_var(Tile<L>& t, int act) {
   if (act == AMBER_ACT_TANH) {
-#pragma unroll
-    for (int fb = 0; fb < L / 32; ++fb)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) t.a[fb][i] = tanh_fast(t.a[fb][i]);
+    tile_tanh<L>(t);
   } else {
     tile_act_fast<L>(t, act);
   }

@@ -308,6 +308,43 @@ def test_3d_like_and_hierarchical_graphs_match_oracle(gpu_device):
     assert got.shape == want.shape and close(got.cpu(), want)
 
 
+@pytest.mark.parametrize("latent,steps", [(128, 4), (64, 6)])
+@pytest.mark.parametrize("act,residual,layer_norm", [("tanh", "inner", "inner"), ("tanh", None, None), ("leakyrelu", "outer", "outer"),
+                                                     ("relu", "outer", "inner"), ("leakyrelu", "inner", "outer"),
+                                                     ("tanh", "outer", None), ("leakyrelu", None, "outer")])
+def test_tanh_and_outer_modes_mid_size_match_oracle(gpu_device, latent, steps, act, residual, layer_norm):
+    """Round 3: tanh and the "outer" residual / LayerNorm modes (message_passing_block.py:62-74, 127-128; latent_mlp.py:76-83)
+    on the feature-per-lane kernels' general instantiations - several tiles a wave, hub rows of hundreds of edges, partial
+    last tiles, a partial mask; node AND edge latents (the stored e' is the value after the outer operations, the aggregate
+    is taken before them) and the sizing output against the oracle."""
+    torch.manual_seed(latent + steps)
+    cfg = {"latent_dimension": latent, "create_graph_copy": True, "assert_graph_shapes": False, "edge_dropout": 0.0, "embedding": None,
+           "stack": {"layer_norm": layer_norm, "num_steps": steps, "residual_connections": residual,
+                     "mlp": {"activation_function": act, "num_layers": 2}},
+           "decoder": {"activation_function": "tanh" if act == "tanh" else "leakyrelu", "num_layers": 2,
+                       "regularization": {"dropout": 0, "spectral_norm": False, "latent_normalization": None}}}
+    rng = np.random.default_rng(17)
+    parts = [syn.hierarchical_graph(47, 39, 3, 2, rng), syn.hierarchical_graph(31, 28, 2, 2, rng)]
+    g = syn.make_batch([p[0] for p in parts], [p[1] for p in parts], 4, 2, mask_outputs=[p[2] for p in parts])
+    model = SupervisedMPN(AttrDict(cfg), syn.GraphBatch(x=torch.zeros(1, 4), edge_attr=torch.zeros(1, 2)))
+    with torch.no_grad():
+        for name, prm in model.named_parameters():
+            if "layer_norm" in name:
+                prm.add_(0.1 * torch.randn(prm.shape))
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    ocfg = dict(cfg, in_node_features=4, in_edge_features=2)
+    want = orc.supervised_mpn_forward(sd, ocfg, g.x, g.edge_attr, g.edge_index, g.mask_output)
+    want_x, want_e = orc.mpn_forward(sd, ocfg, g.x, g.edge_attr, g.edge_index, prefix="mpn.")
+    model = model.to(gpu_device).eval()
+    gd = g.to(gpu_device)
+    with torch.no_grad():
+        got = model(gd)
+        nodes, edges, _ = model.mpn(gd)
+    assert got.shape == want.shape and close(got.cpu(), want)
+    assert close(nodes["node"].cpu(), want_x)
+    assert close(edges["edges"]["edge_attr"].cpu(), want_e)
+
+
 # ------------------------------------------------------------------------------------------------------
 # full BASELINE size: size-independent properties
 # ------------------------------------------------------------------------------------------------------
