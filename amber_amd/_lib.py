@@ -162,7 +162,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.amber_mpn_abi_version() != 1:
+    if lib.amber_mpn_abi_version() != 2:
         raise RuntimeError("amber_amd: libamber_mpn.so ABI version mismatch; rebuild it")
     _lib = lib
     return lib

@@ -55,6 +55,10 @@ __global__ void project_kernel(const int32_t* __restrict__ rowptr, const int32_t
 
 __device__ inline void atomic_max_f64(double* addr, double v) {
   unsigned long long* a = reinterpret_cast<unsigned long long*>(addr);
+  if (v != v) {  // np.maximum propagates a nan candidate (and keeps a nan that is already there: `nan < v` is false below)
+    atomicExch(a, static_cast<unsigned long long>(__double_as_longlong(v)));
+    return;
+  }
   unsigned long long old = *a;
   while (__longlong_as_double(static_cast<long long>(old)) < v) {  // np.maximum: keeps the larger; order-independent
     const unsigned long long seen = atomicCAS(a, old, static_cast<unsigned long long>(__double_as_longlong(v)));
@@ -65,12 +69,20 @@ __device__ inline void atomic_max_f64(double* addr, double v) {
 
 // one gradation pass, first half: the lower bounds both ends of every edge impose on each other, from the field as it
 // stands BEFORE the pass (sizing_field_util.py:172-181)
-__global__ void gradation_bounds_kernel(const int64_t* __restrict__ edges, int64_t Me, const double* __restrict__ pos, int dim,
+// a vertex id outside [0, V) is clamped (memory-safe) and reported through `flag` (the reference's numpy indexing raises)
+__device__ inline int64_t checked_vertex(int64_t v, int64_t V, int32_t* flag) {
+  if (v < 0 || v >= V) {
+    *flag = 1;  // every writer stores the same value
+    return v < 0 ? 0 : V - 1;
+  }
+  return v;
+}
+__global__ void gradation_bounds_kernel(const int64_t* __restrict__ edges, int64_t Me, int64_t V, const double* __restrict__ pos, int dim,
                                         const double* __restrict__ field, double gradation, double* __restrict__ m0,
-                                        double* __restrict__ m1) {
+                                        double* __restrict__ m1, int32_t* __restrict__ flag) {
   for (int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < Me;
        e += static_cast<int64_t>(gridDim.x) * blockDim.x) {
-    const int64_t a = edges[e], b = edges[Me + e];
+    const int64_t a = checked_vertex(edges[e], V, flag), b = checked_vertex(edges[Me + e], V, flag);
     double d2 = 0.0;
     for (int c = 0; c < dim; ++c) {
       const double d = pos[a * dim + c] - pos[b * dim + c];
@@ -84,12 +96,12 @@ __global__ void gradation_bounds_kernel(const int64_t* __restrict__ edges, int64
   }
 }
 // second half: np.maximum.at on both ends (the maximum does not depend on the order of the updates)
-__global__ void gradation_apply_kernel(const int64_t* __restrict__ edges, int64_t Me, const double* __restrict__ m0,
-                                       const double* __restrict__ m1, double* __restrict__ field) {
+__global__ void gradation_apply_kernel(const int64_t* __restrict__ edges, int64_t Me, int64_t V, const double* __restrict__ m0,
+                                       const double* __restrict__ m1, double* __restrict__ field, int32_t* __restrict__ flag) {
   for (int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < Me;
        e += static_cast<int64_t>(gridDim.x) * blockDim.x) {
-    atomic_max_f64(field + edges[e], m0[e]);
-    atomic_max_f64(field + edges[Me + e], m1[e]);
+    atomic_max_f64(field + checked_vertex(edges[e], V, flag), m0[e]);
+    atomic_max_f64(field + checked_vertex(edges[Me + e], V, flag), m1[e]);
   }
 }
 
@@ -100,10 +112,10 @@ __device__ inline double edge_length_to_volume(double s, int dim) {  // geometry
 // per-block partial sums of volume / predicted volume, in element order inside a block; blocks are added in order by
 // density_final_kernel (deterministic; numpy's pairwise sum differs from it in the last bits only)
 constexpr int kDensityBlock = 256;
-__global__ __launch_bounds__(kDensityBlock) void density_partial_kernel(const int64_t* __restrict__ t, int k, int64_t M,
+__global__ __launch_bounds__(kDensityBlock) void density_partial_kernel(const int64_t* __restrict__ t, int k, int64_t M, int64_t V,
                                                                         const double* __restrict__ vol,
                                                                         const double* __restrict__ field, int vertex_field, int dim,
-                                                                        double* __restrict__ part) {
+                                                                        double* __restrict__ part, int32_t* __restrict__ flag) {
   __shared__ double red[kDensityBlock];
   double s = 0.0;
   for (int64_t m = static_cast<int64_t>(blockIdx.x) * kDensityBlock + threadIdx.x; m < M;
@@ -111,7 +123,7 @@ __global__ __launch_bounds__(kDensityBlock) void density_partial_kernel(const in
     double sz;
     if (vertex_field) {  // mean of the simplex' vertex values (:187)
       double acc = 0.0;
-      for (int j = 0; j < k; ++j) acc += field[t[static_cast<int64_t>(j) * M + m]];
+      for (int j = 0; j < k; ++j) acc += field[checked_vertex(t[static_cast<int64_t>(j) * M + m], V, flag)];
       sz = acc / k;
     } else {
       sz = field[m];
@@ -126,11 +138,13 @@ __global__ __launch_bounds__(kDensityBlock) void density_partial_kernel(const in
   }
   if (threadIdx.x == 0) part[blockIdx.x] = red[0];
 }
-__global__ void density_final_kernel(const double* __restrict__ part, int n, double factor, double* __restrict__ out) {
+__global__ void density_final_kernel(const double* __restrict__ part, int n, double factor, const int32_t* __restrict__ flag,
+                                     double* __restrict__ out) {
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     double s = 0.0;
     for (int i = 0; i < n; ++i) s += part[i];
     out[0] = s * factor;
+    out[1] = flag[0] ? 1.0 : 0.0;  // a vertex id was out of range (clamped): the caller raises, as numpy's indexing would
   }
 }
 
@@ -166,7 +180,7 @@ hipError_t launch_project_elements(const int64_t* t, int k, int64_t M, int64_t V
 }
 
 size_t estimate_workspace_bytes(int64_t V, int64_t Me) {
-  return align256(8 * static_cast<size_t>(V)) + 2 * align256(8 * static_cast<size_t>(Me)) + align256(8 * kDensityGrid);
+  return align256(8 * static_cast<size_t>(V)) + 2 * align256(8 * static_cast<size_t>(Me)) + align256(8 * kDensityGrid) + 256;
 }
 
 hipError_t launch_estimate_elements(const int64_t* t, int k, int64_t M, int64_t V, const double* vol, const double* field,
@@ -180,21 +194,25 @@ hipError_t launch_estimate_elements(const int64_t* t, int k, int64_t M, int64_t 
   double* m1 = reinterpret_cast<double*>(p);
   p += align256(8 * static_cast<size_t>(Me));
   double* part = reinterpret_cast<double*>(p);
+  p += align256(8 * kDensityGrid);
+  int32_t* flag = reinterpret_cast<int32_t*>(p);
+  hipError_t e0 = hipMemsetAsync(flag, 0, sizeof(int32_t), s);
+  if (e0 != hipSuccess) return e0;
   const double* use = field;
   if (vertex_field) {
     hipError_t e = hipMemcpyAsync(smooth, field, 8 * static_cast<size_t>(V), hipMemcpyDeviceToDevice, s);  // sizing_field.copy()
     if (e != hipSuccess) return e;
     for (int pass = 0; pass < 2 && Me > 0; ++pass) {
-      hipLaunchKernelGGL(gradation_bounds_kernel, dim3(grid_for(Me, 256)), dim3(256), 0, s, edges, Me, pos, dim, smooth, gradation, m0, m1);
-      hipLaunchKernelGGL(gradation_apply_kernel, dim3(grid_for(Me, 256)), dim3(256), 0, s, edges, Me, m0, m1, smooth);
+      hipLaunchKernelGGL(gradation_bounds_kernel, dim3(grid_for(Me, 256)), dim3(256), 0, s, edges, Me, V, pos, dim, smooth, gradation, m0, m1, flag);
+      hipLaunchKernelGGL(gradation_apply_kernel, dim3(grid_for(Me, 256)), dim3(256), 0, s, edges, Me, V, m0, m1, smooth, flag);
     }
     use = smooth;
   }
   int grid = static_cast<int>(cdiv(M > 0 ? M : 1, kDensityBlock));
   if (grid > kDensityGrid) grid = kDensityGrid;
-  hipLaunchKernelGGL(density_partial_kernel, dim3(grid), dim3(kDensityBlock), 0, s, t, k, M, vol, use, vertex_field, dim, part);
+  hipLaunchKernelGGL(density_partial_kernel, dim3(grid), dim3(kDensityBlock), 0, s, t, k, M, V, vol, use, vertex_field, dim, part, flag);
   const double factor = (vertex_field && dim == 3) ? 0.618 : 1.0;  // :192-194
-  hipLaunchKernelGGL(density_final_kernel, dim3(1), dim3(64), 0, s, part, grid, factor, out);
+  hipLaunchKernelGGL(density_final_kernel, dim3(1), dim3(64), 0, s, part, grid, factor, flag, out);
   return hipGetLastError();
 }
 

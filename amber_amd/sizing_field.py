@@ -81,11 +81,14 @@ def mesh_sizing_field_to_num_elements(mesh, sizing_field, node_type: Optional[st
             raise ValueError(f"one sizing value per vertex expected ({v}), given {sf.numel()}")
     elif sf.numel() != m:
         raise ValueError(f"one sizing value per element expected ({m}), given {sf.numel()}")
-    out = torch.empty(1, dtype=torch.float64, device=device)
+    out = torch.empty(2, dtype=torch.float64, device=device)  # [estimate, "an id was out of range" flag]
     ws = torch.empty(lib.amber_mpn_estimate_workspace_bytes(v, me), dtype=torch.uint8, device=device)
     with torch.cuda.device(device):
         rc = lib.amber_mpn_estimate_num_elements(t.data_ptr(), k, m, v, vol.data_ptr(), sf.data_ptr(), 1 if vertex else 0, dim,
                                                  _lib.ptr(edges), me, _lib.ptr(pos), float(gradation), out.data_ptr(),
                                                  ws.data_ptr(), ws.numel(), _lib.stream_ptr(device))
     _lib.check(rc, "estimate_num_elements")
-    return float(out.item())
+    res = out.cpu()
+    if float(res[1]) != 0.0:
+        raise IndexError(f"mesh.t / mesh.mesh_edges contain vertex ids outside [0, {v})")
+    return float(res[0])

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define AMBER_MPN_ABI_VERSION 1
+#define AMBER_MPN_ABI_VERSION 2
 #define AMBER_MPN_MAX_MLP_LAYERS 4
 #define AMBER_MPN_TILE 32 /* sorted edges (or nodes) per wave tile */
 
@@ -58,10 +58,15 @@ enum { AMBER_NORM_NONE = 0, AMBER_NORM_LAYER = 1, AMBER_NORM_AFFINE = 2 /* Batch
 /* precision of the MLP contractions */
 enum {
   AMBER_PREC_FP32 = 0, /* exact fp32 MFMA (v_mfma_f32_32x32x2_f32): a k-ordered fmaf chain */
-  AMBER_PREC_F16X2 = 1, /* fp32-grade split precision: operands as hi + lo fp16 pairs (22 bits) with exact
-                           power-of-two tile / matrix scaling, 3 fp16 MFMAs per product, fp32 accumulate; meets the
-                           fp32 tolerance (1e-5).  Used by the edge and node kernels where the configuration allows
-                           it (relu / leakyrelu, no "outer" modes, weights fit LDS), otherwise the exact path runs. */
+  AMBER_PREC_F16X2 = 1, /* fp32-grade split precision, meets the fp32 tolerance (1e-5).  The edge and node kernels of the
+                           stack (relu / leakyrelu / tanh, every residual / LayerNorm mode, 1..2 weight matrices that fit
+                           LDS at the latent width; latent <= 128) and a relu / leakyrelu / tanh decoder without latent
+                           normalisation run feature-per-lane on hi + lo fp16 operand pairs (22 bits, exact power-of-two
+                           tile / matrix scaling, 3 fp16 MFMAs per product, fp32 accumulate).  Everything those kernels
+                           do not take - latent 256, MLP embeddings, decoders with other activations or a latent
+                           normalisation, the stand-alone amber_mpn_head, more hidden matrices than fit LDS - runs on the
+                           row-per-lane kernels with bf16x3 operands (three bf16 pieces a float, six piece products,
+                           <= 2^-22 a product) at latent 128 and 256, and as exact fp32 MFMA chains at latent 32 / 64. */
   AMBER_PREC_F16 = 2    /* reduced precision: the same kernels with plain fp16 operands (one MFMA per product, fp32
                            accumulate, fp32 storage of all features); tolerance 1e-2, the bound BASELINE's north star
                            gives for bf16-class MLPs.  Never the default. */
@@ -71,7 +76,7 @@ enum {
  * config/algorithm/architecture/mpn.yaml ("Config / flags"). */
 typedef struct AmberMpnDesc {
   int32_t latent;             /* latent_dimension: 32, 64, 128, or 256 (256: row-per-lane kernels - exact fp32 for AMBER_PREC_FP32,
-                                 bf16x3 operands otherwise; backward exact fp32) */
+                                 bf16x3 operands otherwise, see AMBER_PREC_F16X2; backward at 256 exact fp32) */
   int32_t num_steps;          /* stack.num_steps: blocks with their own weights */
   int32_t num_step_repeats;   /* stack.num_step_repeats: each block applied this often */
   int32_t mlp_layers;         /* stack.mlp.num_layers, 1..AMBER_MPN_MAX_MLP_LAYERS */
@@ -368,8 +373,11 @@ int amber_mpn_build_inter_edges(const AmberGraphDesc* gdesc, int64_t num_src, in
  * (_mesh_sizing_field_to_num_elements, sizing_field_util.py:128-200).  vertex_field = 1: sizing_field [V] on the vertices,
  * smoothed by two gradation passes over the mesh edges (edges [2, Me] int64 = mesh.mesh_edges, positions [V, dim] float64;
  * np.maximum.at becomes an order-independent atomic maximum), averaged per element, times 0.618 in 3D; vertex_field = 0:
- * sizing_field [M] on the elements (edges / positions unused).  out: float64[1] on the device.  Equal to the reference
- * within 1e-12 relative (pow and the order of the final sum differ in the last bits).
+ * sizing_field [M] on the elements (edges / positions unused).  out: float64[2] on the device - out[0] the estimate, out[1]
+ * 1.0 if a vertex id of `simplices` / `edges` lay outside [0, num_vertices) (it was clamped; the reference's numpy indexing
+ * raises IndexError, and so does the Python wrapper), else 0.0 (ABI version 2; version 1 wrote out[0] only and did
+ * not check the ids).  A nan in the sizing field propagates through the gradation maximum as in np.maximum.at.  Equal to
+ * the reference within 1e-12 relative (pow and the order of the final sum differ in the last bits).
  * ------------------------------------------------------------------------------------------------- */
 size_t amber_mpn_project_workspace_bytes(int32_t verts_per_element, int64_t num_elements, int64_t num_vertices);
 int amber_mpn_project_elements_to_vertices(const int64_t* simplices, int32_t verts_per_element, int64_t num_elements,

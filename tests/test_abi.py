@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_abi_version_and_struct_size():
     lib = _lib.load()
-    assert lib.amber_mpn_abi_version() == 1
+    assert lib.amber_mpn_abi_version() == 2
     assert C.sizeof(_lib.AmberMpnDesc) == 17 * 4
 
 

@@ -64,6 +64,22 @@ def test_refinement_step_sized_mesh_and_errors(gpu_device):
         sf.project_elements_to_vertices(bad, np.ones(1), device=gpu_device)
     with pytest.raises(ValueError, match="one value and one volume per element"):
         sf.project_elements_to_vertices(mesh, vals[:-1], device=gpu_device)
+    # the estimate validates its vertex ids too: a bad id in mesh.t or in mesh.mesh_edges raises, as numpy would
+    with pytest.raises(IndexError):
+        sf.mesh_sizing_field_to_num_elements(bad, np.ones(3), node_type="vertex", device=gpu_device)
+    e_bad = e.copy()
+    e_bad[1, 3] = pos.shape[0] + 4
+    with pytest.raises(IndexError):
+        sf.mesh_sizing_field_to_num_elements(_Mesh(t, pos, vol, e_bad), field, node_type="vertex", device=gpu_device)
+    e_neg = e.copy()
+    e_neg[0, 0] = -1
+    with pytest.raises(IndexError):
+        sf.mesh_sizing_field_to_num_elements(_Mesh(t, pos, vol, e_neg), field, node_type="vertex", device=gpu_device)
+    # a nan in the vertex field propagates through the gradation maximum (np.maximum.at) into the estimate
+    f_nan = field.copy()
+    f_nan[5] = np.nan
+    assert np.isnan(mo.mesh_sizing_field_to_num_elements(t, vol, f_nan, "vertex", 2, e, pos))
+    assert np.isnan(sf.mesh_sizing_field_to_num_elements(mesh, f_nan, node_type="vertex", device=gpu_device))
     # tensors already on the GPU are used where they are
     tm = _Mesh(torch.from_numpy(t).to(gpu_device), pos, torch.from_numpy(vol).to(gpu_device), e)
     out = sf.project_elements_to_vertices(tm, torch.from_numpy(vals).to(gpu_device), device=gpu_device, as_tensor=True)
