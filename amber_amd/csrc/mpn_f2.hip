@@ -141,6 +141,9 @@ DEVINL float tile_absmax(const Tile<L>& t) {
 DEVINL void split4(const f32x4 x, float scale, half4& hi, half4& lo) {
   typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
   u32x2 hh, ll;
+  // (Round 3 checked these four statements as a suspect for the rare wrong rows described at launch_edge_f2_general: they
+  // are not - a build with the split written in plain C showed the same errors, and the compiler does keep the wait state
+  // between a half-register write and its reader here: it sees the operands of an asm statement.)
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
     unsigned hv, lv;
@@ -465,11 +468,20 @@ DEVINL void half_sum16(float (&v)[16]) {
 }
 // LayerNorm over the features of every row of a tile in accumulator layout: across the lanes of a half, one register a row
 template <int L>
+DEVINL void tile_layernorm_acc_pre(Tile<L>& acc, const float (&g)[L / 32], const float (&bt)[L / 32], float eps);
+template <int L>
 DEVINL void tile_layernorm_acc(Tile<L>& acc, const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int n) {
   constexpr int NFB = L / 32;
   float g[NFB], bt[NFB];
   piece_load<L>(gamma + NFB * n, g);
   piece_load<L>(beta + NFB * n, bt);
+  tile_layernorm_acc_pre<L>(acc, g, bt, eps);
+}
+// ... with this lane's gamma / beta already in registers (fetched at the tile's top where registers allow: on a one-mesh
+// graph a launch is one tile's dependent chain, and every small load inside it is an exposed round trip to L2)
+template <int L>
+DEVINL void tile_layernorm_acc_pre(Tile<L>& acc, const float (&g)[L / 32], const float (&bt)[L / 32], float eps) {
+  constexpr int NFB = L / 32;
   float s[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
@@ -718,6 +730,22 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
     }
     if constexpr (!EMB && !PREFETCH_E) load_et(tile, hq, nq);
     gather_ps(sx0, nq);
+    // L <= 64 (registers allow it): the tile-invariant vectors - the last hidden layer's bias, LayerNorm gamma / beta - are
+    // fetched with the tile's first loads instead of where they are used (each an exposed round trip to L2 on a one-mesh graph)
+#ifndef AMBER_EDGE_EARLY_MAXL
+#define AMBER_EDGE_EARLY_MAXL 64
+#endif
+    constexpr bool EARLY = L <= AMBER_EDGE_EARLY_MAXL;
+    float e_b1[NFB], e_g[NFB], e_bt[NFB];
+#pragma unroll
+    for (int fb = 0; fb < NFB; ++fb) e_b1[fb] = e_g[fb] = e_bt[fb] = 0.f;
+    if constexpr (EARLY) {
+      if (a.nl > 1) piece_load<L>(a.layers[a.nl - 1].b + NFB * nq, e_b1);
+      if (a.layer_norm != AMBER_MODE_NONE) {
+        piece_load<L>(a.gamma + NFB * nq, e_g);
+        piece_load<L>(a.beta + NFB * nq, e_bt);
+      }
+    }
     Tile<L> acc = pn;
     // The per-destination sums run per HALF over its own sixteen positions (reduction tiles of 16 edges, red_shift 4):
     // first / last destination of this half's positions and where their rows begin / end
@@ -794,7 +822,12 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
     auto hidden_layer = [&](int l, auto&& hook) {
       const float* wg = a.layers[l].w;
       float bv[NFB];
-      piece_load<L>(a.layers[l].b + NFB * nq, bv);
+      if (EARLY && l == a.nl - 1) {
+#pragma unroll
+        for (int fb = 0; fb < NFB; ++fb) bv[fb] = e_b1[fb];
+      } else {
+        piece_load<L>(a.layers[l].b + NFB * nq, bv);
+      }
       pow2_scale(wave_max(tile_absmax<L>(acc)), scale, inv);
       // accumulate from zero (the first MFMA of a block takes the constant 0 as its C operand: no 64 moves to seed the
       // accumulators) and add the bias with the multiply that takes the result back out of the scaled domain
@@ -841,7 +874,10 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
       load_et(has_next ? tnext : tile, hq, nq);
     STAMP(7);  // residual
     // ---- LayerNorm over the features of every edge: across the lanes of a half, one register per edge ----
-    if (a.layer_norm == AMBER_MODE_INNER && !DBG(64)) tile_layernorm_acc<L>(acc, a.gamma, a.beta, a.eps, nq);
+    if (a.layer_norm == AMBER_MODE_INNER && !DBG(64)) {
+      if constexpr (EARLY) tile_layernorm_acc_pre<L>(acc, e_g, e_bt, a.eps);
+      else tile_layernorm_acc<L>(acc, a.gamma, a.beta, a.eps, nq);
+    }
     STAMP(8);  // LayerNorm
     // "outer" residual / LayerNorm (VAR = 1 only): what the node module aggregates is the value at THIS point
     // (message_passing_block.py:119-123), so the per-destination sums run first and the outer operations, then the stores
@@ -946,7 +982,10 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
     if constexpr (GEN) {
       if (outer_ops) {
         if (a.residual == AMBER_MODE_OUTER) add_residual();
-        if (a.layer_norm == AMBER_MODE_OUTER) tile_layernorm_acc<L>(acc, a.gamma, a.beta, a.eps, nq);
+        if (a.layer_norm == AMBER_MODE_OUTER) {
+          if constexpr (EARLY) tile_layernorm_acc_pre<L>(acc, e_g, e_bt, a.eps);
+          else tile_layernorm_acc<L>(acc, a.gamma, a.beta, a.eps, nq);
+        }
       }
     }
     }  // pass == 0
@@ -1120,6 +1159,26 @@ __global__ __launch_bounds__(64 * node_waves<L>()) void node_kernel_f2(const Nod
 #endif
     Tile<L> v;  // the tile's node features in accumulator layout (after the update: x')
     int k = 0;
+    // L <= 64 (registers allow it): the tile-invariant vectors of the update - first- and second-layer bias, LayerNorm gamma /
+    // beta - are fetched HERE, with the tile's first loads, instead of where they are used
+#ifndef AMBER_NODE_EARLY_MAXL
+#define AMBER_NODE_EARLY_MAXL 64
+#endif
+    constexpr bool EARLY = L <= AMBER_NODE_EARLY_MAXL;
+    constexpr bool EARLY_HD = L <= 32 && EARLY;  // (at 64 the extra landing registers spill 15-50)
+    float e_b0[NFB], e_b1[NFB], e_g[NFB], e_bt[NFB];
+#pragma unroll
+    for (int fb = 0; fb < NFB; ++fb) e_b0[fb] = e_b1[fb] = e_g[fb] = e_bt[fb] = 0.f;
+    if constexpr (EARLY) {
+      if (a.do_update) {
+        piece_load<L>(a.b0 + NFB * nq, e_b0);
+        if (a.nl > 1) piece_load<L>(a.layers[1].b + NFB * nq, e_b1);
+        if (a.layer_norm != AMBER_MODE_NONE) {
+          piece_load<L>(a.gamma + NFB * nq, e_g);
+          piece_load<L>(a.beta + NFB * nq, e_bt);
+        }
+      }
+    }
     if (a.do_update) {
       // in-degrees and reduction slots of the tile's rows (used by the aggregate phase, loaded a phase ahead)
       int dg[4], tf[4], tl[4];
@@ -1136,6 +1195,7 @@ __global__ __launch_bounds__(64 * node_waves<L>()) void node_kernel_f2(const Nod
       Tile<L> acc;
       float scale, inv;
       ELanding<L> lg;  // whole row pieces of the aggregate
+      ELanding<L> hd;  // ... and of the first head slot of rows a reduction tile's border cut
       {
         // ---- whole row pieces of x ----
         ELanding<L> lx;
@@ -1163,6 +1223,11 @@ __global__ __launch_bounds__(64 * node_waves<L>()) void node_kernel_f2(const Nod
             for (int it = 0; it < 4; ++it) {
               const float* src = tl[it] != tf[it] ? a.tail + static_cast<int64_t>(tf[it]) * L : a.agg + nd[it] * L;
               lg.v[ps][it] = (reinterpret_cast<const f32x4*>(src) + (lq & 7))[ps * 8];
+              if constexpr (EARLY_HD) {  // the first head slot of a cut row in the same breath (L = 32: registers allow it)
+                hd.v[ps][it] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (tl[it] != tf[it])
+                  hd.v[ps][it] = (reinterpret_cast<const f32x4*>(a.head + static_cast<int64_t>(tf[it] + 1) * L) + (lq & 7))[ps * 8];
+              }
             }
           });
         else
@@ -1184,7 +1249,10 @@ __global__ __launch_bounds__(64 * node_waves<L>()) void node_kernel_f2(const Nod
         // ---- whole row pieces of the aggregate: sums of the edge kernel -> mean.  After the row of sums: the first
         // head slot of a cut row; rows cut more than once (longer than a reduction tile) add their further heads in a loop.
         {
-          ELanding<L> hd;
+#if !defined(AMBER_NODE_NO_PREFETCH_AGG)
+          if (!EARLY_HD || DBG(256))
+#endif
+          {
 #pragma unroll
           for (int it = 0; it < 4; ++it) {
 #pragma unroll
@@ -1194,6 +1262,7 @@ __global__ __launch_bounds__(64 * node_waves<L>()) void node_kernel_f2(const Nod
 #pragma unroll
               for (int ps = 0; ps < NFB; ++ps) hd.v[ps][it] = ph[ps * 8];
             }
+          }
           }
 #pragma unroll
           for (int it = 0; it < 4; ++it)
@@ -1228,7 +1297,12 @@ __global__ __launch_bounds__(64 * node_waves<L>()) void node_kernel_f2(const Nod
         {
           const float post = ig * a.w0x[L * L];
           float bv[NFB];
-          piece_load<L>(a.b0 + NFB * nq, bv);
+          if constexpr (EARLY) {
+#pragma unroll
+            for (int fb = 0; fb < NFB; ++fb) bv[fb] = e_b0[fb];
+          } else {
+            piece_load<L>(a.b0 + NFB * nq, bv);
+          }
 #pragma unroll
           for (int fb = 0; fb < NFB; ++fb) {
 #pragma unroll
@@ -1252,7 +1326,12 @@ __global__ __launch_bounds__(64 * node_waves<L>()) void node_kernel_f2(const Nod
         {
           const float post = inv * wg[L * L];
           float bv[NFB];
-          piece_load<L>(a.layers[l].b + NFB * nq, bv);
+          if (EARLY && l == 1) {
+#pragma unroll
+            for (int fb = 0; fb < NFB; ++fb) bv[fb] = e_b1[fb];
+          } else {
+            piece_load<L>(a.layers[l].b + NFB * nq, bv);
+          }
 #pragma unroll
           for (int fb = 0; fb < NFB; ++fb) {
 #pragma unroll
@@ -1262,6 +1341,10 @@ __global__ __launch_bounds__(64 * node_waves<L>()) void node_kernel_f2(const Nod
         if constexpr (VAR == 0) tile_act_fast<L>(nxt, a.act); else if constexpr (VAR == 2) tile_tanh<L>(nxt); else tile_act_var<L>(nxt, a.act);
         acc = nxt;
       }
+      auto node_ln = [&](Tile<L>& t) __attribute__((always_inline)) {
+        if constexpr (EARLY) tile_layernorm_acc_pre<L>(t, e_g, e_bt, a.eps);
+        else tile_layernorm_acc<L>(t, a.gamma, a.beta, a.eps, nq);
+      };
       auto add_x_residual = [&]() __attribute__((always_inline)) {
         AMBER_REPIN_H4;
         if (nvalid == kTile) {
@@ -1290,16 +1373,16 @@ __global__ __launch_bounds__(64 * node_waves<L>()) void node_kernel_f2(const Nod
       if constexpr ((VAR & 1) == 0) {
         // order of message_passing_block.py:124-125: inner residual, inner LayerNorm
         if (a.residual == AMBER_MODE_INNER) add_x_residual();
-        if (a.layer_norm == AMBER_MODE_INNER && !DBG(4096)) tile_layernorm_acc<L>(acc, a.gamma, a.beta, a.eps, nq);
+        if (a.layer_norm == AMBER_MODE_INNER && !DBG(4096)) node_ln(acc);
       } else {
         // message_passing_block.py:124-128: inner residual, inner LayerNorm, outer residual, outer LayerNorm.  Node rows have
         // no consumer in between, so only residual-outer + LayerNorm-inner differs from "residual, then LayerNorm"
         if (a.residual == AMBER_MODE_OUTER && a.layer_norm == AMBER_MODE_INNER) {
-          tile_layernorm_acc<L>(acc, a.gamma, a.beta, a.eps, nq);
+          node_ln(acc);
           add_x_residual();
         } else {
           if (a.residual != AMBER_MODE_NONE) add_x_residual();
-          if (a.layer_norm != AMBER_MODE_NONE) tile_layernorm_acc<L>(acc, a.gamma, a.beta, a.eps, nq);
+          if (a.layer_norm != AMBER_MODE_NONE) node_ln(acc);
         }
       }
       v = acc;
@@ -1460,6 +1543,7 @@ __global__ __launch_bounds__(64 * node_waves<L>()) void node_kernel_f2(const Nod
 #endif
 }
 
+#ifndef AMBER_F2_GENERAL_TU
 // ---------------------------------------------------------------------------------------------------
 // weight packing: absmax -> power-of-two scale -> hi/lo fp16 in B-operand order (+ header)
 // ---------------------------------------------------------------------------------------------------
@@ -1541,6 +1625,8 @@ hipError_t launch_pack_f2(int L, const float* W, int ld, int col0, int scale_col
   return launch_pack_f2_batch(L, b, s);
 }
 
+#endif  // !AMBER_F2_GENERAL_TU
+
 // hipFuncAttributeMaxDynamicSharedMemorySize once per (kernel, device, size): a runtime call per launch is what a
 // forward on a small graph (42 launches of ~30 us) can do without
 static hipError_t allow_dynamic_lds(const void* fn, size_t lds) {
@@ -1570,6 +1656,7 @@ static int64_t persistent_grid(int num_cus, int64_t ntiles, int waves) {
   return need < grid ? (need < 8 ? 8 : need) : grid;
 }
 
+#ifndef AMBER_F2_GENERAL_TU
 size_t edge_f2_lds_bytes(int L, int nl) {
   const int waves = L == 64 ? edge_waves<64>() : (L == 32 ? edge_waves<32>() : kF2Waves);
   return static_cast<size_t>(nl) * L * L * 4 + static_cast<size_t>(waves) * kWinBytes;
@@ -1577,9 +1664,21 @@ size_t edge_f2_lds_bytes(int L, int nl) {
 
 bool edge_f2_supported(int L, int nl, int act, int residual, int layer_norm) {
   (void)residual;
-  (void)layer_norm;  // every residual / LayerNorm mode: the outer ones and tanh run on the general instantiation (VAR = 1)
+  (void)layer_norm;  // every residual / LayerNorm mode: the outer ones and tanh run on the general instantiations (VAR = 1, 2)
   return (act == AMBER_ACT_RELU || act == AMBER_ACT_LEAKYRELU || act == AMBER_ACT_TANH) && edge_f2_lds_bytes(L, nl) <= 160 * 1024;
 }
+#else
+size_t edge_f2_lds_bytes(int L, int nl);
+#endif
+// The general instantiations (VAR != 0) live in a translation unit of their own, mpn_f2_general.hip = this file compiled
+// with -DAMBER_F2_GENERAL_TU and WITHOUT the SLP vectoriser.  Round 3 found why: vectorised over pairs of tile rows, the
+// fused-embedding variants of those instantiations feed v_pk_fma_f32 straight from v_mov_b32_dpp results, and on the
+// MI355X that code returned - rarely, differently from run to run - a wrong value for the even row of a pair in lanes
+// 32-63 (one edge row off by percents; -fno-slp-vectorize: gone, 12 runs bit-equal; the cause inside the hardware /
+// hazard tables was not isolated).  The default instantiations (VAR = 0) contain no such pattern
+// (checked on the ISA) and are pinned by the run-to-run bit-equality tests at full size.
+hipError_t launch_edge_f2_general(int L, int var, const EdgeArgs& a, int num_cus, hipStream_t s);
+hipError_t launch_node_f2_general(int L, const NodeArgs& a, int num_cus, hipStream_t s);
 // which instantiation: 1 = general (an "outer" residual / LayerNorm; takes tanh too), 2 = the default structure with tanh
 static int f2_variant(int act, int residual, int layer_norm) {
   if (residual == AMBER_MODE_OUTER || layer_norm == AMBER_MODE_OUTER) return 1;
@@ -1619,26 +1718,31 @@ static hipError_t launch_edge_f2_v(const EdgeArgs& a, int num_cus, hipStream_t s
   if (a.single) return a.emb_on ? launch_edge_f2_t<L, true, false, VAR>(a, num_cus, s) : launch_edge_f2_t<L, false, false, VAR>(a, num_cus, s);
   return a.emb_on ? launch_edge_f2_t<L, true, true, VAR>(a, num_cus, s) : launch_edge_f2_t<L, false, true, VAR>(a, num_cus, s);
 }
-template <int L>
-static hipError_t launch_edge_f2_l(const EdgeArgs& a, int num_cus, hipStream_t s) {
-  switch (f2_variant(a.act, a.residual, a.layer_norm)) {
-    case 1: return launch_edge_f2_v<L, 1>(a, num_cus, s);
-    case 2: return launch_edge_f2_v<L, 2>(a, num_cus, s);
-    default: return launch_edge_f2_v<L, 0>(a, num_cus, s);
-  }
-}
-
-hipError_t launch_edge_f2(int L, const EdgeArgs& a, int num_cus, hipStream_t s) {
-  if (a.E == 0) return hipSuccess;
-  if (a.emb_on && (a.emb_f < 0 || a.emb_f > kMaxFusedEmbed || !a.emb_b || !a.emb_w0 || !a.perm)) return hipErrorInvalidValue;
+#ifdef AMBER_F2_GENERAL_TU
+hipError_t launch_edge_f2_general(int L, int var, const EdgeArgs& a, int num_cus, hipStream_t s) {
   switch (L) {
-    case 32: return launch_edge_f2_l<32>(a, num_cus, s);
-    case 64: return launch_edge_f2_l<64>(a, num_cus, s);
-    case 128: return launch_edge_f2_l<128>(a, num_cus, s);
+    case 32: return var == 1 ? launch_edge_f2_v<32, 1>(a, num_cus, s) : launch_edge_f2_v<32, 2>(a, num_cus, s);
+    case 64: return var == 1 ? launch_edge_f2_v<64, 1>(a, num_cus, s) : launch_edge_f2_v<64, 2>(a, num_cus, s);
+    case 128: return var == 1 ? launch_edge_f2_v<128, 1>(a, num_cus, s) : launch_edge_f2_v<128, 2>(a, num_cus, s);
     default: return hipErrorInvalidValue;
   }
 }
+#else
+hipError_t launch_edge_f2(int L, const EdgeArgs& a, int num_cus, hipStream_t s) {
+  if (a.E == 0) return hipSuccess;
+  if (a.emb_on && (a.emb_f < 0 || a.emb_f > kMaxFusedEmbed || !a.emb_b || !a.emb_w0 || !a.perm)) return hipErrorInvalidValue;
+  const int var = f2_variant(a.act, a.residual, a.layer_norm);
+  if (var != 0) return launch_edge_f2_general(L, var, a, num_cus, s);
+  switch (L) {
+    case 32: return launch_edge_f2_v<32, 0>(a, num_cus, s);
+    case 64: return launch_edge_f2_v<64, 0>(a, num_cus, s);
+    case 128: return launch_edge_f2_v<128, 0>(a, num_cus, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+#endif
 
+#ifndef AMBER_F2_GENERAL_TU
 bool node_f2_supported(int L, int act, int residual, int layer_norm) {
   (void)residual;
   (void)layer_norm;  // every mode: see f2_general
@@ -1649,6 +1753,7 @@ bool head_f2_supported(int n_dense, int dense_act, int dense_norm) {
   return n_dense >= 1 && (dense_act == AMBER_ACT_RELU || dense_act == AMBER_ACT_LEAKYRELU || dense_act == AMBER_ACT_TANH) &&
          dense_norm == AMBER_NORM_NONE;
 }
+#endif  // !AMBER_F2_GENERAL_TU
 
 template <int L, bool SPLIT, bool HEAD, int VAR>
 static hipError_t launch_node_f2_t(const NodeArgs& a, int num_cus, hipStream_t s) {
@@ -1690,19 +1795,27 @@ static hipError_t launch_node_f2_v(const NodeArgs& a, int num_cus, hipStream_t s
   if (a.single) return head ? launch_node_f2_t<L, false, true, VAR>(a, num_cus, s) : launch_node_f2_t<L, false, false, VAR>(a, num_cus, s);
   return head ? launch_node_f2_t<L, true, true, VAR>(a, num_cus, s) : launch_node_f2_t<L, true, false, VAR>(a, num_cus, s);
 }
-template <int L>
-static hipError_t launch_node_f2_l(const NodeArgs& a, int num_cus, hipStream_t s) {
-  // (the node kernel's general instantiation costs nothing measurable: one variant serves tanh and the outer order)
-  const bool general = (a.do_update && f2_variant(a.act, a.residual, a.layer_norm) != 0) || (a.do_readout && a.dense_act == AMBER_ACT_TANH);
-  return general ? launch_node_f2_v<L, 1>(a, num_cus, s) : launch_node_f2_v<L, 0>(a, num_cus, s);
-}
-hipError_t launch_node_f2(int L, const NodeArgs& a, int num_cus, hipStream_t s) {
+#ifdef AMBER_F2_GENERAL_TU
+hipError_t launch_node_f2_general(int L, const NodeArgs& a, int num_cus, hipStream_t s) {
   switch (L) {
-    case 32: return launch_node_f2_l<32>(a, num_cus, s);
-    case 64: return launch_node_f2_l<64>(a, num_cus, s);
-    case 128: return launch_node_f2_l<128>(a, num_cus, s);
+    case 32: return launch_node_f2_v<32, 1>(a, num_cus, s);
+    case 64: return launch_node_f2_v<64, 1>(a, num_cus, s);
+    case 128: return launch_node_f2_v<128, 1>(a, num_cus, s);
     default: return hipErrorInvalidValue;
   }
 }
+#else
+hipError_t launch_node_f2(int L, const NodeArgs& a, int num_cus, hipStream_t s) {
+  // (the node kernel's general instantiation costs nothing measurable: one variant serves tanh and the outer order)
+  const bool general = (a.do_update && f2_variant(a.act, a.residual, a.layer_norm) != 0) || (a.do_readout && a.dense_act == AMBER_ACT_TANH);
+  if (general) return launch_node_f2_general(L, a, num_cus, s);
+  switch (L) {
+    case 32: return launch_node_f2_v<32, 0>(a, num_cus, s);
+    case 64: return launch_node_f2_v<64, 0>(a, num_cus, s);
+    case 128: return launch_node_f2_v<128, 0>(a, num_cus, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+#endif
 
 }  // namespace amber
