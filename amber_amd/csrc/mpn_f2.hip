@@ -1670,14 +1670,16 @@ bool edge_f2_supported(int L, int nl, int act, int residual, int layer_norm) {
 #else
 size_t edge_f2_lds_bytes(int L, int nl);
 #endif
-// The general instantiations (VAR != 0) live in a translation unit of their own, mpn_f2_general.hip = this file compiled
-// with -DAMBER_F2_GENERAL_TU and WITHOUT the SLP vectoriser.  Round 3 found why: vectorised over pairs of tile rows, the
-// fused-embedding variants of those instantiations feed v_pk_fma_f32 straight from v_mov_b32_dpp results, and on the
-// MI355X that code returned - rarely, differently from run to run - a wrong value for the even row of a pair in lanes
-// 32-63 (one edge row off by percents; -fno-slp-vectorize: gone, 12 runs bit-equal; the cause inside the hardware /
-// hazard tables was not isolated).  The default instantiations (VAR = 0) contain no such pattern
-// (checked on the ISA) and are pinned by the run-to-run bit-equality tests at full size.
+// The general instantiations (VAR != 0) live in translation units of their own (this file compiled with
+// -DAMBER_F2_GENERAL_TU=1 / =2: build time, and the default instantiations' code generation stays untouched by them).
+// Round 3 met rare, run-dependent wrong rows in these instantiations (an even edge row of a tile in lanes 32-63 with the
+// fused embedding; the last node row of a tile in the outer-residual node kernel) and traced them to ONE instruction form
+// the SLP vectoriser emits: a packed fp32 operation whose low result selects the high register of src1
+// (v_pk_add_f32 / v_pk_fma_f32 ... op_sel:[0,1,..]).  Every translation unit of the library now goes through
+// csrc/pkfix.py, which exchanges src0 and src1 of such instructions between compiler and assembler (the same selection on
+// src0 is sound); tools/check_isa.py verifies the shipped library.  The experiments are in DESIGN.md section 5.3.
 hipError_t launch_edge_f2_general(int L, int var, const EdgeArgs& a, int num_cus, hipStream_t s);
+hipError_t launch_edge_f2_general_emb(int L, int var, const EdgeArgs& a, int num_cus, hipStream_t s);
 hipError_t launch_node_f2_general(int L, const NodeArgs& a, int num_cus, hipStream_t s);
 // which instantiation: 1 = general (an "outer" residual / LayerNorm; takes tanh too), 2 = the default structure with tanh
 static int f2_variant(int act, int residual, int layer_norm) {
@@ -1713,13 +1715,26 @@ static hipError_t launch_edge_f2_t(const EdgeArgs& a, int num_cus, hipStream_t s
 #endif
   return hipGetLastError();
 }
+// AMBER_F2_GENERAL_TU: 1 = the general instantiations without the fused edge embedding (and the node kernel's), 2 = the general
+// instantiations WITH the fused edge embedding (mpn_f2_general_emb.hip)
 template <int L, int VAR>
 static hipError_t launch_edge_f2_v(const EdgeArgs& a, int num_cus, hipStream_t s) {
+#if !defined(AMBER_F2_GENERAL_TU)
   if (a.single) return a.emb_on ? launch_edge_f2_t<L, true, false, VAR>(a, num_cus, s) : launch_edge_f2_t<L, false, false, VAR>(a, num_cus, s);
   return a.emb_on ? launch_edge_f2_t<L, true, true, VAR>(a, num_cus, s) : launch_edge_f2_t<L, false, true, VAR>(a, num_cus, s);
+#elif AMBER_F2_GENERAL_TU == 1
+  return a.single ? launch_edge_f2_t<L, false, false, VAR>(a, num_cus, s) : launch_edge_f2_t<L, false, true, VAR>(a, num_cus, s);
+#else
+  return a.single ? launch_edge_f2_t<L, true, false, VAR>(a, num_cus, s) : launch_edge_f2_t<L, true, true, VAR>(a, num_cus, s);
+#endif
 }
 #ifdef AMBER_F2_GENERAL_TU
+#if AMBER_F2_GENERAL_TU == 1
 hipError_t launch_edge_f2_general(int L, int var, const EdgeArgs& a, int num_cus, hipStream_t s) {
+  if (a.emb_on) return launch_edge_f2_general_emb(L, var, a, num_cus, s);
+#else
+hipError_t launch_edge_f2_general_emb(int L, int var, const EdgeArgs& a, int num_cus, hipStream_t s) {
+#endif
   switch (L) {
     case 32: return var == 1 ? launch_edge_f2_v<32, 1>(a, num_cus, s) : launch_edge_f2_v<32, 2>(a, num_cus, s);
     case 64: return var == 1 ? launch_edge_f2_v<64, 1>(a, num_cus, s) : launch_edge_f2_v<64, 2>(a, num_cus, s);
@@ -1795,7 +1810,9 @@ static hipError_t launch_node_f2_v(const NodeArgs& a, int num_cus, hipStream_t s
   if (a.single) return head ? launch_node_f2_t<L, false, true, VAR>(a, num_cus, s) : launch_node_f2_t<L, false, false, VAR>(a, num_cus, s);
   return head ? launch_node_f2_t<L, true, true, VAR>(a, num_cus, s) : launch_node_f2_t<L, true, false, VAR>(a, num_cus, s);
 }
-#ifdef AMBER_F2_GENERAL_TU
+#if defined(AMBER_F2_GENERAL_TU) && AMBER_F2_GENERAL_TU == 2
+// (the node kernels are in the other general translation unit)
+#elif defined(AMBER_F2_GENERAL_TU)
 hipError_t launch_node_f2_general(int L, const NodeArgs& a, int num_cus, hipStream_t s) {
   switch (L) {
     case 32: return launch_node_f2_v<32, 1>(a, num_cus, s);

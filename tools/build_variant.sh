@@ -9,9 +9,9 @@ make -s -j8 >/dev/null
 mkdir -p variants
 extra=""
 [ "$unit" = "mesh.hip" ] && extra="-ffp-contract=off"
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function $extra "$@" -c "$unit" -o "variants/${name}_${unit%.hip}.o"
+./build_tu.sh "$unit" "variants/${name}_${unit%.hip}.o" -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function $extra "$@" | grep -v "^pkfix:" || true
 objs=""
-for o in api mpn_kernels mpn_f2 mpn_bwd csr glue graph mesh; do
+for o in api mpn_kernels mpn_f2 mpn_f2_general mpn_f2_general_emb mpn_bwd csr glue graph mesh; do
   if [ "$o" = "${unit%.hip}" ]; then objs="$objs variants/${name}_$o.o"; else objs="$objs $o.o"; fi
 done
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 $objs -o "variants/libamber_$name.so"
