@@ -840,12 +840,19 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
         for (int ps = 0; ps < NFB; ++ps) hook(ps);
       }
       const float post = inv * wg[L * L];
+#ifdef AMBER_EPI_PK
+      if constexpr (VAR == 0) {
+        tile_bias_act_pk<L>(nxt, post, bv, a.act);
+      } else
+#endif
+      {
 #pragma unroll
-      for (int fb = 0; fb < NFB; ++fb) {
+        for (int fb = 0; fb < NFB; ++fb) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) nxt.a[fb][i] = fmaf(nxt.a[fb][i], post, bv[fb]);
+          for (int i = 0; i < 16; ++i) nxt.a[fb][i] = fmaf(nxt.a[fb][i], post, bv[fb]);
+        }
+        if constexpr (VAR == 0) tile_act_fast<L>(nxt, a.act); else if constexpr (VAR == 2) tile_tanh<L>(nxt); else tile_act_var<L>(nxt, a.act);
       }
-      if constexpr (VAR == 0) tile_act_fast<L>(nxt, a.act); else if constexpr (VAR == 2) tile_tanh<L>(nxt); else tile_act_var<L>(nxt, a.act);
       acc = nxt;
     };
 #pragma unroll 1

@@ -285,6 +285,28 @@ DEVINL void tile_act_fast(Tile<L>& t, int act) {
 #endif
 }
 
+// t = act(t * post + bias) with relu / leakyrelu, the multiply-adds and the slope multiply as packed fp32 operations on
+// the accumulator's register pairs (rows 2j, 2j + 1 of one feature block): half the instructions of the scalar form, the
+// same roundings (fused multiply-add, one multiply).  AMBER_EPI_PK selects it in the kernels' layer epilogues.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int L>
+DEVINL void tile_bias_act_pk(Tile<L>& t, float post, const float (&bv)[L / 32], int act) {
+  const float slope = act == AMBER_ACT_LEAKYRELU ? 0.01f : 0.f;
+  const f32x2 post2 = {post, post}, slope2 = {slope, slope};
+#pragma unroll
+  for (int fb = 0; fb < L / 32; ++fb) {
+    const f32x2 b2 = {bv[fb], bv[fb]};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      f32x2 p = {t.a[fb][2 * j], t.a[fb][2 * j + 1]};
+      p = __builtin_elementwise_fma(p, post2, b2);
+      const f32x2 q = p * slope2;
+      t.a[fb][2 * j] = fmaxf(p.x, q.x);
+      t.a[fb][2 * j + 1] = fmaxf(p.y, q.y);
+    }
+  }
+}
+
 // tanh on accumulator registers for the feature-per-lane kernels (no LDS trip, no library call), two ranges that share one
 // v_rcp_f32:  |x| < 0.8: the Pade [5/4] form as a CORRECTION to x,  tanh x = x - x x^2 (315 + 14 x^2) / (945 + 420 x^2 + 15 x^4)
 // (truncation < 5e-9 there; the roundings only touch the correction, so tiny arguments keep their relative accuracy);
