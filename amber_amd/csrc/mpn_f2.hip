@@ -507,7 +507,11 @@ DEVINL void tile_layernorm_acc_pre(Tile<L>& acc, const float (&g)[L / 32], const
   for (int i = 0; i < 16; ++i) {
     const float rstd = __builtin_amdgcn_rsqf(s[i] * (1.0f / L) + eps);  // v_rsq_f32: 1 ulp
 #pragma unroll
-    for (int fb = 0; fb < NFB; ++fb) acc.a[fb][i] = acc.a[fb][i] * rstd * g[fb] + bt[fb];
+    for (int fb = 0; fb < NFB; ++fb) {
+      // (scalar here - so that the result lands in the store's register quad without a move - was tried in round 3: the edge
+      // kernel at L = 128 then spills 66 registers)
+      acc.a[fb][i] = acc.a[fb][i] * rstd * g[fb] + bt[fb];
+    }
   }
 }
 
@@ -770,7 +774,7 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
     } else {
       pow2_scale(wave_max(tile_absmax<L>(et)), scale, inv);
       STAMP(2);  // e rows arrived, tile maximum
-      tile_scale<L>(acc, scale * wscale0);
+      tile_scale_rows<L>(acc, scale * wscale0);  // (the gathered rows sit in row-piece order: see tile_scale_rows)
       STAMP(3);  // P_s rows arrived
     }
     // destination terms P_d[dst] (rows repeat inside a tile: L1 / L2 hits) join after the contraction, when the landing
@@ -869,7 +873,7 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
         embed_tile(e0);
         tile_add<L>(acc, e0);
       } else {
-        tile_add<L>(acc, et);  // the rows of e, still in their registers
+        tile_add_rows<L>(acc, et);  // the rows of e, still in their registers (row-piece order: see tile_add_rows)
       }
     };
     if (EMB && a.residual == AMBER_MODE_INNER) {
@@ -978,7 +982,11 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
             }
           }
 #pragma unroll
-          for (int fb = 0; fb < NFB; ++fb) sum[fb] += (!GEN || i + 16 * h < nvalid) ? acc.a[fb][i] : 0.f;
+          for (int fb = 0; fb < NFB; ++fb) {
+            float r = sum[fb] + ((!GEN || i + 16 * h < nvalid) ? acc.a[fb][i] : 0.f);
+            asm("" : "+v"(r));  // scalar: paired over feature blocks the addends would be gathered with two moves a pair
+            sum[fb] = r;
+          }
         }
         if (nvh > 0) {
           float* const dstp = (!sb && ends_last) ? aggn + static_cast<size_t>(static_cast<unsigned>(lastd)) * L : (sb ? slot_head : slot_tail);

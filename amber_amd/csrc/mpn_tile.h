@@ -263,6 +263,33 @@ DEVINL void tile_scale(Tile<L>& t, float factor) {
   for (int fb = 0; fb < L / 32; ++fb) t.a[fb] = t.a[fb] * factor;
 }
 
+// The same two operations element by element, for tiles that arrived as row pieces (a lane's L/32 consecutive features of
+// one row per load): their registers sit in [row][feature block] order, and the vector forms above - packed fp32
+// instructions on register pairs [feature block][row, row + 1] - make the compiler gather every pair with two moves first
+// (3 instructions for 2 values; measured in the ISA).  Scalar: one instruction a value, the "transpose" is free.
+template <int L>
+DEVINL void tile_scale_rows(Tile<L>& t, float factor) {
+#pragma unroll
+  for (int fb = 0; fb < L / 32; ++fb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      float r = t.a[fb][i] * factor;
+      asm("" : "+v"(r));  // opaque to the SLP vectoriser, which would pair the rows again (and gather the pairs with moves)
+      t.a[fb][i] = r;
+    }
+}
+template <int L>
+DEVINL void tile_add_rows(Tile<L>& t, const Tile<L>& o) {
+#pragma unroll
+  for (int fb = 0; fb < L / 32; ++fb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      float r = t.a[fb][i] + o.a[fb][i];
+      asm("" : "+v"(r));
+      t.a[fb][i] = r;
+    }
+}
+
 template <int L>
 DEVINL void tile_act_fast(Tile<L>& t, int act) {
   const float slope = act == AMBER_ACT_LEAKYRELU ? 0.01f : 0.f;
