@@ -466,6 +466,46 @@ DEVINL void half_sum16(float (&v)[16]) {
     v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
   }
 }
+// The same sums as a reduce-scatter (round 3): every step halves the number of registers instead of repeating all sixteen -
+// lanes whose bit k is 0 keep the even register of a pair and hand the odd one to their partner l ^ 2^k, the others the other
+// way round - so that after the four steps inside a row of 16 lanes and the exchange between the two rows of a half, lane l
+// holds the half's total of value l & 15: 8 + 4 + 2 + 1 additions (each with two selects and the partner exchange) instead of
+// 5 x 16, and whatever follows per value (the mean's scale, the inverse deviation: an FMA and a quarter-rate v_rsq_f32) is done
+// ONCE, in that lane, before row_bcast hands every lane the sixteen results.  The partners and the order of the additions are
+// those of half_sum16 (a + b = b + a): the totals are bit-identical.
+template <int CTRL, int BANKS>
+DEVINL float dpp_into(float old, float src) {  // lanes of the banks in BANKS take src through CTRL, the others keep old
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), CTRL, 0xf, BANKS, false));
+}
+DEVINL float half_reduce_scatter16(const float (&v)[16]) {
+  const int l = threadIdx.x;  // bits 0..3: the lane's place in its row of 16
+  const bool b0 = (l & 1) != 0, b1 = (l & 2) != 0, b2 = (l & 4) != 0, b3 = (l & 8) != 0;
+  float w[8], x[4], y[2];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float send = b0 ? v[2 * k] : v[2 * k + 1], keep = b0 ? v[2 * k + 1] : v[2 * k];
+    w[k] = keep + AMBER_DPP_F(send, 0xB1);  // quad_perm [1,0,3,2]: l ^ 1
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float send = b1 ? w[2 * k] : w[2 * k + 1], keep = b1 ? w[2 * k + 1] : w[2 * k];
+    x[k] = keep + AMBER_DPP_F(send, 0x4E);  // quad_perm [2,3,0,1]: l ^ 2
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const float send = b2 ? x[2 * k] : x[2 * k + 1], keep = b2 ? x[2 * k + 1] : x[2 * k];
+    float t = dpp_into<0x104, 0x5>(send, send);  // row_shl:4 into the lanes with bit 2 clear (banks 0, 2): from l + 4
+    t = dpp_into<0x114, 0xA>(t, send);           // row_shr:4 into the lanes with bit 2 set (banks 1, 3): from l - 4
+    y[k] = keep + t;
+  }
+  const float send = b3 ? y[0] : y[1], keep = b3 ? y[1] : y[0];
+  const float z = keep + AMBER_DPP_F(send, 0x128);  // row_ror:8: l ^ 8
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(z), __float_as_uint(z), false, false);  // the half's other row
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+#ifndef AMBER_LN_SCATTER
+#define AMBER_LN_SCATTER 1
+#endif
 // LayerNorm over the features of every row of a tile in accumulator layout: across the lanes of a half, one register a row
 template <int L>
 DEVINL void tile_layernorm_acc_pre(Tile<L>& acc, const float (&g)[L / 32], const float (&bt)[L / 32], float eps);
@@ -489,10 +529,18 @@ DEVINL void tile_layernorm_acc_pre(Tile<L>& acc, const float (&g)[L / 32], const
 #pragma unroll
     for (int fb = 1; fb < NFB; ++fb) s[i] += acc.a[fb][i];
   }
+#if AMBER_LN_SCATTER
+  const float mean_l = half_reduce_scatter16(s) * (1.0f / L);  // lane l: the mean of row l & 15
+#else
   half_sum16(s);
+#endif
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
+#if AMBER_LN_SCATTER
+    const float mean = __int_as_float(row_bcast(__float_as_int(mean_l), i));
+#else
     const float mean = s[i] * (1.0f / L);
+#endif
     float q = 0.f;
 #pragma unroll
     for (int fb = 0; fb < NFB; ++fb) {
@@ -502,10 +550,18 @@ DEVINL void tile_layernorm_acc_pre(Tile<L>& acc, const float (&g)[L / 32], const
     }
     s[i] = q;
   }
+#if AMBER_LN_SCATTER
+  const float rstd_l = __builtin_amdgcn_rsqf(half_reduce_scatter16(s) * (1.0f / L) + eps);  // v_rsq_f32: 1 ulp; lane l: row l & 15
+#else
   half_sum16(s);
+#endif
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
+#if AMBER_LN_SCATTER
+    const float rstd = __int_as_float(row_bcast(__float_as_int(rstd_l), i));
+#else
     const float rstd = __builtin_amdgcn_rsqf(s[i] * (1.0f / L) + eps);  // v_rsq_f32: 1 ulp
+#endif
 #pragma unroll
     for (int fb = 0; fb < NFB; ++fb) {
       // (scalar here - so that the result lands in the store's register quad without a move - was tried in round 3: the edge
