@@ -662,14 +662,23 @@ __global__ __launch_bounds__(64 * edge_waves<L>()) void edge_kernel_f2(const Edg
     const int64_t q0 = t * kTile;
     const int nv = (a.E - q0) < kTile ? static_cast<int>(a.E - q0) : kTile;
     const float* const rows = a.e + q0 * L;
+    // (two loops under a real, wave-uniform branch: with the test inside one loop the compiler computed BOTH address forms for
+    // every row and selected between them - 57 vector instructions to issue 16 loads; the empty asm keeps the arms apart)
+    if (nv == kTile) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      float pc[NFB];
-      if (nv == kTile)  // one address per group of rows, rows inside it are immediate offsets
+      for (int i = 0; i < 16; ++i) {  // one address per group of rows, rows inside it are immediate offsets
+        float pc[NFB];
         piece_load<L>(rows + static_cast<unsigned>(hq_) + kRowGroup<L> * (i / kRowGroup<L>) * L + (i % kRowGroup<L>) * L, pc);
-      else  // rows beyond the end repeat the last edge and are never stored
+        tile_set_piece<L>(et, i, pc);
+      }
+    } else {
+      asm volatile("; partial tile");
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {  // rows beyond the end repeat the last edge and are never stored
+        float pc[NFB];
         piece_load<L>(rows + static_cast<unsigned>(min(i + 16 * h, nv - 1) * L + NFB * nq_), pc);
-      tile_set_piece<L>(et, i, pc);
+        tile_set_piece<L>(et, i, pc);
+      }
     }
   };
   constexpr bool PREFETCH_E = !EMB && AMBER_EDGE_PREFETCH_E != 0 && !GEN;
