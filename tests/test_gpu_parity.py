@@ -502,3 +502,26 @@ def test_deferred_verdict_survives_a_dropped_csr_and_the_training_path_collects_
     with pytest.raises(IndexError):
         model(g).sum().backward()
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("latent", [64, 128])
+@pytest.mark.parametrize("act,residual,layer_norm", [("relu", "outer", "inner"), ("tanh", None, None), ("leakyrelu", "inner", "inner")])
+def test_forty_forwards_are_bit_equal(gpu_device, latent, act, residual, layer_norm):
+    """The detector of DESIGN.md section 5.3: a library whose general translation unit was built without the pkfix rewrite gives
+    14 distinct results in 150 one-step forwards of the outer-residual configuration (68 with two steps) on this graph; a sound
+    one gives one.  Forty forwards with one and with two steps, node and edge latents bit for bit."""
+    g = syn.grid_batch(num_graphs=2, nx=40, ny=30, in_edge_features=2).to(gpu_device)
+    for steps in (1, 2):
+        torch.manual_seed(latent + steps)
+        cfg = {"latent_dimension": latent, "create_graph_copy": True, "assert_graph_shapes": False, "edge_dropout": 0.0, "embedding": None,
+               "stack": {"layer_norm": layer_norm, "num_steps": steps, "residual_connections": residual,
+                         "mlp": {"activation_function": act, "num_layers": 2}},
+               "decoder": {"activation_function": "leakyrelu", "num_layers": 2,
+                           "regularization": {"dropout": 0, "spectral_norm": False, "latent_normalization": None}}}
+        model = SupervisedMPN(AttrDict(cfg), syn.GraphBatch(x=torch.zeros(1, 4), edge_attr=torch.zeros(1, 2))).to(gpu_device).eval()
+        with torch.no_grad():
+            nodes, edges, _ = model.mpn(g)
+            first = (nodes["node"].clone(), edges["edges"]["edge_attr"].clone())
+            for k in range(39):
+                nodes, edges, _ = model.mpn(g)
+                assert torch.equal(nodes["node"], first[0]) and torch.equal(edges["edges"]["edge_attr"], first[1]), (steps, k)
