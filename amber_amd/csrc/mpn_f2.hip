@@ -477,6 +477,41 @@ template <int CTRL, int BANKS>
 DEVINL float dpp_into(float old, float src) {  // lanes of the banks in BANKS take src through CTRL, the others keep old
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), CTRL, 0xf, BANKS, false));
 }
+#ifndef AMBER_LN_BANKED
+#define AMBER_LN_BANKED 1
+#endif
+#if AMBER_LN_BANKED
+// out = a + a[partner] in the lanes of the banks BA, b + b[partner] in the lanes of the banks BB (a bank = 4 lanes of a row of
+// 16); the partner through the DPP control.  Two v_add_f32_dpp under bank masks: no select.  (s_nop 1: a DPP operand needs two
+// wait states after the instruction that wrote it, and the compiler does not see the DPP inside the asm.)
+#define AMBER_BANKED_ADD(out, a, b, CA, BA, CB, BB)                                                                       \
+  asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 " CA " row_mask:0xf bank_mask:" BA "\n\tv_add_f32_dpp %0, %2, %2 " CB       \
+      " row_mask:0xf bank_mask:" BB                                                                                       \
+      : "=&v"(out)                                                                                                        \
+      : "v"(a), "v"(b))
+DEVINL float half_reduce_scatter16(const float (&v)[16]) {
+  const int l = threadIdx.x;  // bits 0..3: the lane's place in its row of 16
+  const bool b0 = (l & 1) != 0, b1 = (l & 2) != 0;
+  float w[8], x[4], y[2];
+  // the two steps whose partners differ in a whole bank come first (8 and 4 results, two instructions each)
+#pragma unroll
+  for (int k = 0; k < 8; ++k) AMBER_BANKED_ADD(w[k], v[2 * k], v[2 * k + 1], "row_ror:8", "0x3", "row_ror:8", "0xc");  // l ^ 8
+#pragma unroll
+  for (int k = 0; k < 4; ++k) AMBER_BANKED_ADD(x[k], w[2 * k], w[2 * k + 1], "row_shl:4", "0x5", "row_shr:4", "0xa");  // l ^ 4
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const float send = b1 ? x[2 * k] : x[2 * k + 1], keep = b1 ? x[2 * k + 1] : x[2 * k];
+    y[k] = keep + AMBER_DPP_F(send, 0x4E);  // quad_perm [2,3,0,1]: l ^ 2
+  }
+  const float send = b0 ? y[0] : y[1], keep = b0 ? y[1] : y[0];
+  const float z = keep + AMBER_DPP_F(send, 0xB1);  // quad_perm [1,0,3,2]: l ^ 1
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(z), __float_as_uint(z), false, false);  // the half's other row
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// which lane of a row ends with value i in that order: bit 3 of the lane chose between v[2k] / v[2k + 1] (bit 0 of i), bit 2
+// between w[2k] / w[2k + 1] (bit 1 of i), bit 1 bit 2 of i, bit 0 bit 3 of i
+constexpr int ln_lane_of(int i) { return ((i & 1) << 3) | ((i & 2) << 1) | ((i & 4) >> 1) | ((i & 8) >> 3); }
+#else
 DEVINL float half_reduce_scatter16(const float (&v)[16]) {
   const int l = threadIdx.x;  // bits 0..3: the lane's place in its row of 16
   const bool b0 = (l & 1) != 0, b1 = (l & 2) != 0, b2 = (l & 4) != 0, b3 = (l & 8) != 0;
@@ -503,6 +538,8 @@ DEVINL float half_reduce_scatter16(const float (&v)[16]) {
   const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(z), __float_as_uint(z), false, false);  // the half's other row
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
+constexpr int ln_lane_of(int i) { return i; }
+#endif
 #ifndef AMBER_LN_SCATTER
 #define AMBER_LN_SCATTER 1
 #endif
@@ -537,7 +574,7 @@ DEVINL void tile_layernorm_acc_pre(Tile<L>& acc, const float (&g)[L / 32], const
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
 #if AMBER_LN_SCATTER
-    const float mean = __int_as_float(row_bcast(__float_as_int(mean_l), i));
+    const float mean = __int_as_float(row_bcast(__float_as_int(mean_l), ln_lane_of(i)));
 #else
     const float mean = s[i] * (1.0f / L);
 #endif
@@ -558,7 +595,7 @@ DEVINL void tile_layernorm_acc_pre(Tile<L>& acc, const float (&g)[L / 32], const
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
 #if AMBER_LN_SCATTER
-    const float rstd = __int_as_float(row_bcast(__float_as_int(rstd_l), i));
+    const float rstd = __int_as_float(row_bcast(__float_as_int(rstd_l), ln_lane_of(i)));
 #else
     const float rstd = __builtin_amdgcn_rsqf(s[i] * (1.0f / L) + eps);  // v_rsq_f32: 1 ulp
 #endif
